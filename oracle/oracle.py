@@ -1,0 +1,127 @@
+"""TEST INFRASTRUCTURE — ctypes binding of oracle/libtarok_oracle.so (the CPU
+restatement of the reference rules).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this; the product never does."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtarok_oracle.so")
+
+
+class ToGame(C.Structure):
+    _fields_ = [
+        ("hand", C.c_uint64 * 4), ("pile", C.c_uint64 * 4),
+        ("talon", C.c_uint8 * 6), ("trick", C.c_uint8 * 4),
+        ("n_in_trick", C.c_uint8), ("leader", C.c_uint8), ("trick_no", C.c_uint8),
+        ("contract", C.c_uint8), ("declarer", C.c_uint8), ("king", C.c_int8),
+        ("team", C.c_uint8), ("talon_left", C.c_uint8), ("choice", C.c_int8),
+        ("phase", C.c_uint8), ("error", C.c_uint8), ("score", C.c_int16 * 4),
+    ]
+
+
+def build(force=False):
+    src = os.path.join(HERE, "tarok_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    u64, i64, i32, u32 = C.c_uint64, C.c_int64, C.c_int, C.c_uint32
+    P = C.POINTER
+    L.to_prestej.restype = i32; L.to_prestej.argtypes = [u64]
+    L.to_vrednost.restype = i32; L.to_vrednost.argtypes = [i32]
+    L.to_discardable.restype = u64; L.to_discardable.argtypes = [u64]
+    L.to_legal_navadna.restype = u64; L.to_legal_navadna.argtypes = [u64, i32]
+    L.to_legal_klop.restype = u64; L.to_legal_klop.argtypes = [u64, i32]
+    L.to_trick_winner.restype = i32; L.to_trick_winner.argtypes = [P(C.c_uint8)]
+    L.to_new_game.restype = None; L.to_new_game.argtypes = [P(ToGame), P(C.c_uint8), i32, i32, i32]
+    L.to_exchange.restype = i32; L.to_exchange.argtypes = [P(ToGame), i32, P(C.c_uint8)]
+    L.to_seat.restype = i32; L.to_seat.argtypes = [P(ToGame)]
+    L.to_legal.restype = u64; L.to_legal.argtypes = [P(ToGame)]
+    L.to_step.restype = i32; L.to_step.argtypes = [P(ToGame), i32]
+    L.to_export_lanes.restype = None; L.to_export_lanes.argtypes = [P(ToGame), P(u64)]
+    L.to_game_key.restype = u64; L.to_game_key.argtypes = [u64, u64, u64]
+    L.to_rng32.restype = u32; L.to_rng32.argtypes = [u64, u32]
+    L.to_deal_perm.restype = None; L.to_deal_perm.argtypes = [u64, P(C.c_uint8)]
+    L.to_sample_setup.restype = None; L.to_sample_setup.argtypes = [u64, i32, P(i32), P(i32), P(i32)]
+    L.to_bot_discards.restype = None; L.to_bot_discards.argtypes = [u64, u64, i32, P(C.c_uint8)]
+    L.to_policy_action.restype = i32; L.to_policy_action.argtypes = [u64, i32, u64]
+    L.to_synth_game.restype = None; L.to_synth_game.argtypes = [P(ToGame), u64, u64, u64, i32]
+    vp = C.c_void_p
+    L.to_rollout.restype = i64; L.to_rollout.argtypes = [u64, u64, i64, u64, i32, vp, vp, vp, vp, vp]
+    L.to_rollout_mt.restype = i64; L.to_rollout_mt.argtypes = [i32, u64, u64, i64, u64, i32, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def u8arr(seq):
+    return (C.c_uint8 * len(seq))(*[int(x) for x in seq])
+
+
+class Game:
+    """One game on the CPU oracle."""
+
+    def __init__(self, perm=None, contract=0, declarer=0, king=-1):
+        self.g = ToGame()
+        if perm is not None:
+            lib().to_new_game(C.byref(self.g), u8arr(perm), int(contract), int(declarer), int(king))
+
+    @classmethod
+    def synth(cls, seed, gidx, episode, mix):
+        self = cls()
+        lib().to_synth_game(C.byref(self.g), seed, gidx, episode, mix)
+        return self
+
+    def exchange(self, choice, discards):
+        d = list(discards) + [255] * (3 - len(discards))
+        return lib().to_exchange(C.byref(self.g), int(choice), u8arr(d))
+
+    def seat(self):
+        return lib().to_seat(C.byref(self.g))
+
+    def legal(self):
+        return int(lib().to_legal(C.byref(self.g)))
+
+    def step(self, action):
+        return lib().to_step(C.byref(self.g), int(action))
+
+    def lanes(self):
+        out = (C.c_uint64 * 10)()
+        lib().to_export_lanes(C.byref(self.g), out)
+        return np.array(list(out), dtype=np.uint64)
+
+    @property
+    def done(self):
+        return self.g.phase == 3
+
+    @property
+    def scores(self):
+        return [int(x) for x in self.g.score]
+
+
+def rollout(seed, gidx0, n, episode, mix, threads=1, trace=True):
+    """Random-policy rollouts of synthetic games; returns dict of arrays."""
+    L = lib()
+    out = dict(nsteps=np.zeros(n, np.int16), scores=np.zeros((n, 4), np.int16))
+    if trace:
+        out.update(seats=np.zeros((n, 48), np.int8), masks=np.zeros((n, 48), np.uint64),
+                   actions=np.zeros((n, 48), np.uint8))
+
+    def ptr(name):
+        return out[name].ctypes.data if name in out else None
+    total = L.to_rollout_mt(threads, seed, gidx0, n, episode, mix, ptr("nsteps"), ptr("seats"),
+                            ptr("masks"), ptr("actions"), ptr("scores"))
+    out["total_steps"] = int(total)
+    return out
