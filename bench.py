@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env steps/s at 65,536 parallel 4-player games per MI355X
+(BASELINE.json metric; workload = configs[2]: mixed Klop/Berac/Navadna contracts,
+uniform-random policy, synthetic deals).
+
+    python bench.py --gpus 1 --steps 4800 --warmup 480
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one lock-step of every game = one card played in each of the 65,536
+games of a rank (Tarok.py:48-56): the random-policy kernel writes the action
+array, then tarok_step consumes it (state resident in HBM, observation word out),
+with auto-reset so every slot is live in every step.  value = games x steps x
+ranks / max-over-ranks time.  Weak scaling: each rank owns its own 65,536 games
+(global game indices rank*65536...), no collective in the env path.
+
+Extra objects on the JSON line:
+  roofline      the step kernel against HBM peak: algorithmic 54 B/step
+                x 65,536 games per launch / the kernel's launch duration measured
+                with HIP events bracketing single launches on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/, a C port of the reference rules — test
+                infrastructure, used here only as the reported baseline) on the host
+                cores, bounded sample of the same workload.  rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_STEP = 54
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
+    """Time the CPU oracle on the same synthetic workload (random-policy rollouts
+    of mixed-contract games), all host cores."""
+    from oracle import oracle as O
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    O.rollout(0, 0, 4096, 0, mix, threads=cores, trace=False)          # warm
+    t0 = time.perf_counter()
+    steps, games, ep = 0, 0, 0
+    while True:
+        r = O.rollout(0, 0, n_games_chunk, ep, mix, threads=cores, trace=False)
+        steps += r["total_steps"]
+        games += n_games_chunk
+        ep += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or dt >= max_seconds:
+            break
+    t1 = time.perf_counter()
+    r1 = O.rollout(0, 0, n_games_chunk // 8, 0, mix, threads=1, trace=False)
+    dt1 = time.perf_counter() - t1
+    return {"value": steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d random-policy games (%d steps) of the mixed-contract workload, C oracle, %d threads, %.1f s"
+                      % (games, steps, cores, dt),
+            "single_core_value": r1["total_steps"] / dt1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4800)
+    ap.add_argument("--warmup", type=int, default=480)
+    ap.add_argument("--games", type=int, default=65536, help="games per GPU")
+    ap.add_argument("--graph-chunk", type=int, default=48, help="steps per replayed hipGraph (0 = eager)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
+    args = ap.parse_args()
+
+    import torch
+    from tarok_amd import TarokVecEnv, karte as K, sharding
+
+    rank, local_rank, world_size = sharding.world()
+    if world_size > 1:
+        torch.cuda.set_device(local_rank)
+        sharding.init_process_group("nccl")
+    if args.gpus != world_size and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world_size), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    n = args.games
+    offset, _ = sharding.weak_shard(n, rank)
+    env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
+
+    def run(steps, fused):
+        env.run_random(steps, fused=fused, graph_chunk=args.graph_chunk, auto_reset=True)
+
+    def timed(steps, fused):
+        sharding.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(steps, fused)
+        torch.cuda.synchronize(dev)
+        sharding.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        sharding.max_over_ranks(t)
+        return float(t.item())
+
+    # ---- headline: policy kernel + step kernel per step (the C-ABI step() path)
+    env.reset(episode=0)
+    run(args.warmup, False)
+    dt = timed(args.steps, False)
+    total_steps = n * args.steps * world_size
+    value = total_steps / dt
+    ep, ss = env.counters()
+    episodes_finished = int(ep.sum())
+
+    out = {
+        "metric": "env steps/sec at 65,536 parallel 4-player games; 1/2/4/8 MI355X",
+        "value": value, "unit": "env steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[2]: %d parallel envs per GPU, mixed Klop/Berac/Navadna contracts "
+                               "(1/3 Klop, 1/3 Berac incl. 1/2 open, 1/3 Navadna+Solo over 7 types), uniform random policy, "
+                               "auto-reset" % n,
+                   "games_per_gpu": n, "mode": "tarok_policy_random + tarok_step per step, hipGraph of %d steps" % args.graph_chunk,
+                   "parallelism": "games sharded %d-way, no collective in the env path" % world_size},
+        "episodes_finished_rank0": episodes_finished,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (k_step): HIP events around single launches
+        s = torch.cuda.current_stream(dev)
+        reps = 400
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        env.policy_random()
+        for _ in range(20):
+            env.step(env.action, auto_reset=True)
+            env.policy_random()
+        torch.cuda.synchronize(dev)
+        for e0, e1 in evs:
+            env.policy_random()
+            e0.record(s)
+            env.step(env.action, auto_reset=True)
+            e1.record(s)
+        torch.cuda.synchronize(dev)
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        k_ms = sum(ts[reps // 10: -reps // 10]) / len(ts[reps // 10: -reps // 10])     # trimmed mean
+        algo_bytes = ALGO_BYTES_PER_STEP * n
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": algo_bytes, "kernel_us": k_ms * 1e3,
+                           "kernel_us_min": ts[0] * 1e3,
+                           "note": "54 B/step x %d games per launch / event-bracketed launch duration; "
+                                   "the 2 MB working set is cache resident at this N (see DESIGN.md N-sweep)" % n}
+
+    if not args.no_extras:
+        # ---- side measurements (not `value`): fused policy+step kernel, whole-game rollout kernel
+        env.reset(episode=0)
+        run(args.warmup, True)
+        dtf = timed(args.steps, True)
+        out["fused_step_random"] = {"value": total_steps / dtf, "unit": "env steps/s", "ms_per_step": dtf / args.steps * 1e3}
+        sharding.barrier()
+        torch.cuda.synchronize(dev)
+        r = env.rollout_random(episode=0)
+        torch.cuda.synchronize(dev)
+        reps = 20
+        t0 = time.perf_counter()
+        for e in range(reps):
+            r = env.rollout_random(episode=1 + e)
+        torch.cuda.synchronize(dev)
+        dtr = time.perf_counter() - t0
+        st = torch.tensor([float(r["nsteps"].sum().item()) * reps, dtr], dtype=torch.float64, device=dev)
+        tmax = st[1:2].clone()
+        sharding.max_over_ranks(tmax)
+        cnt = st[0:1].clone()
+        sharding.sum_over_ranks(cnt)
+        out["fused_rollout"] = {"value": float(cnt.item()) / float(tmax.item()), "unit": "env steps/s",
+                                "games_per_s": n * reps * world_size / float(tmax.item()),
+                                "note": "whole games in registers, one launch per 65,536 games; no per-step HBM state"}
+
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(1 << 20, K.MIX_ALL)
+
+    env.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,169 @@
+/* libtarokenv — MI355X-native vectorised Tarok card-play environment, C ABI.
+ *
+ * Drop-in boundary for ONE hot path of anzeA/Tarok: stepping N independent
+ * 4-player games in lock-step — legal-card mask, trick resolution, and
+ * Klop / Berac / Navadna_igra scoring.  It replaces what the reference does in
+ *
+ *     Tarok.paralel_start          Tarok.py:30-62     (N games, 48 lock-steps)
+ *     Igra.razdeli + dispatch      Igra.py:38-55,65-73 (deal -> contract engine)
+ *     Klop / Berac / Navadna_igra  .start()/.krog()/.mozne_karte()/.pobere_stih()
+ *     Roka.prestej                 Roka.py:56-98
+ *
+ * The reference has no FFI: its "plugin API" is the duck-typed Igralec callback
+ * set (Igralec.py:32-122).  Each entry point below names the callback /
+ * generator step it stands in for; INTEGRATION.md shows the ctypes binding and
+ * the Igralec-protocol adapter (tarok_amd/igralec.py) that sits on top.
+ *
+ * Conventions
+ *   - every function returns int: 0 = OK, negative = TAROK_E*; no exceptions.
+ *   - all array arguments are DEVICE pointers owned by the caller (e.g. torch
+ *     tensors' data_ptr()), SoA over the env's N games; NULL where allowed.
+ *   - `stream` is a hipStream_t (NULL = default stream); every call is
+ *     stream-ordered and non-blocking.  One handle per GPU, one host thread per
+ *     handle (the reference is single-threaded cooperative generators).
+ *   - card id = suit*8 + rank-1 (suits KARA=0 SRCE=1 PIK=2 KRIZ=3), taroks
+ *     32..53 (Karta.py:19-23).  Masks are 54-bit sets of card ids.
+ *   - contract code = int(Tip_igre)/10 (Tip_igre.py:4-15): 0 Klop, 1 Tri, 2 Dve,
+ *     3 Ena, 4 Solo_tri, 5 Solo_dve, 6 Solo_ena, 7 Berac, 8 Solo_brez,
+ *     9 Odprti_berac.  Seats are positions in a game's `igralci` list.
+ */
+#ifndef TAROK_ENV_H
+#define TAROK_ENV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAROK_ABI_VERSION 1
+
+#define TAROK_OK 0
+#define TAROK_EINVAL (-1) /* bad argument                                  */
+#define TAROK_EHIP (-2)   /* HIP runtime error: see tarok_last_hip_error() */
+#define TAROK_ENOMEM (-3)
+#define TAROK_ENODEV (-4) /* no usable GPU                                 */
+
+/* synthetic contract mixes used when tarok_reset gets contract == NULL */
+#define TAROK_MIX_ALL 0      /* 1/3 Klop, 1/3 Berac (1/2 open), 1/3 Navadna+Solo over 7 types */
+#define TAROK_MIX_NAVADNA3 1 /* Tri / Dve / Ena uniform                                       */
+#define TAROK_MIX_FIXED 16   /* TAROK_MIX_FIXED + code: every game plays that contract         */
+
+/* flags */
+#define TAROK_DEFER_EXCHANGE 1 /* tarok_reset: leave Tri..Solo_ena games waiting for tarok_exchange */
+#define TAROK_AUTO_RESET 2     /* step kernels: re-deal a game in the launch that finishes it        */
+#define TAROK_CLEAR_COUNTERS 4 /* tarok_reset: also zero the per-slot score sums                     */
+
+/* observation word written by tarok_legal_actions / tarok_step (one u64 per game) */
+#define TAROK_OBS_MASK ((1ULL << 54) - 1) /* [53:0]  legal-card mask of the seat to move  */
+#define TAROK_OBS_SEAT_SHIFT 54           /* [55:54] seat to move                          */
+#define TAROK_OBS_STEP_SHIFT 56           /* [61:56] cards played so far in this game      */
+#define TAROK_OBS_DONE (1ULL << 62)       /* game finished (step: by this very step)       */
+#define TAROK_OBS_ERROR (1ULL << 63)      /* an illegal action was rejected (sticky)       */
+
+/* canonical state lanes of tarok_get_state: lanes_out[lane*N + g] */
+#define TAROK_LANE_HAND0 0 /* 0..3  Igralec.roka[id] of seat s                     */
+#define TAROK_LANE_PILE0 4 /* 4..7  Igralec.kupcek[id] of seat s                   */
+#define TAROK_LANE_TALON 8 /* 6 x 6-bit ordered talon ids (Igra.py:68)             */
+#define TAROK_LANE_META 9
+#define TAROK_NUM_LANES 10
+/* META: [23:0] trick cards 4x6 | [26:24] n_in_trick | [28:27] leader |
+ * [32:29] trick_no | [36:33] contract | [38:37] declarer | [41:39] king (7 none) |
+ * [45:42] team | [48:46] talon_left | [51:49] chosen group (7 none) |
+ * [53:52] phase (1 exchange, 2 play, 3 done) | [54] error                      */
+
+typedef struct tarok_env tarok_env;
+
+const char *tarok_strerror(int code);
+int tarok_abi_version(void);
+int tarok_device_count(void);      /* number of visible GPUs, 0 if none (never fails) */
+int tarok_last_hip_error(void);    /* last hipError_t seen by this library            */
+
+/* One env = n_games slots on one GPU.  game_offset = global index of slot 0
+ * (the deal RNG is keyed by seed, game_offset+g and the slot's episode number,
+ * so any sharding over GPUs plays identical games).  Replaces building N Igra
+ * objects, Tarok.py:33-35. */
+int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_offset,
+                 uint64_t seed, int mix, int flags);
+void tarok_destroy(tarok_env *env);
+int64_t tarok_num_games(const tarok_env *env);
+
+/* Deal and set up every game: Igra.razdeli (Igra.py:65-73) + the contract
+ * engine constructors (Igra.py:38-55; teams Navadna_igra.py:20-30; first
+ * leader Klop.py:26 / Berac.py:15 / Navadna_igra.py:70) + the talon exchange
+ * (Navadna_igra.py:36-66).  Every slot's episode number is set to `episode`.
+ *   deals        [N,54] u8 permutation (hand s = deals[12s:12s+12], talon = deals[48:54]);
+ *                NULL = dealt on device by the spec RNG
+ *   contract     [N] i8 code; NULL = sampled from the env's mix (then declarer
+ *                and king_suit are sampled too)
+ *   declarer     [N] i8 seat 0..3 (ignored for Klop); king_suit [N] i8 0..3 (Tri/Dve/Ena)
+ *   talon_choice [N] i8 chosen talon group, discards [N,3] u8 (255 pad): what
+ *                Igralec.menjaj_iz_talona returns / moves (Igralec.py:161-171);
+ *                NULL = the Bot's exchange (group 0, random discardable cards)
+ *                unless flags has TAROK_DEFER_EXCHANGE. */
+int tarok_reset(tarok_env *env, uint32_t episode, const uint8_t *deals, const int8_t *contract,
+                const int8_t *declarer, const int8_t *king_suit, const int8_t *talon_choice,
+                const uint8_t *discards, int flags, void *stream);
+
+/* menjaj_iz_talona for the games still waiting for it (Navadna_igra.py:60-66).
+ * NULL arrays = the Bot's exchange.  Games not in the exchange phase are untouched. */
+int tarok_exchange(tarok_env *env, const int8_t *talon_choice, const uint8_t *discards, void *stream);
+
+/* mozne_karte for the seat to move in every game (Klop.py:96-133,
+ * Navadna_igra.py:158-168) = the `mozne` handed to pripravi_igraj_karto.
+ * obs_out [N] u64 observation words; seat_out [N] i8 or NULL. */
+int tarok_legal_actions(tarok_env *env, uint64_t *obs_out, int8_t *seat_out, void *stream);
+
+/* One card in every unfinished game = one `next(g)` per game at Tarok.py:54:
+ * the body of krog (Klop.py:47-79, Navadna_igra.py:115-141) after igraj_karto
+ * returned `action`, incl. trick resolution (pobere_stih), the Klop talon gift,
+ * Berac's early end and end-of-game scoring.
+ *   action     [N] u8 card id.  Not in the legal set -> the game is left
+ *              unchanged and its error bit is set (reference: raises Exception,
+ *              Klop.py:57-60).  Finished / waiting games ignore it.
+ *   reward_out [N,4] i16 scores by seat (`pisejo`): written ONLY for games that
+ *              finish in this step; may be NULL
+ *   done_out   [N] u8 1 iff the game finished in this step; may be NULL
+ *   obs_out    [N] u64 observation for the NEXT move (see TAROK_OBS_*)
+ *   flags      TAROK_AUTO_RESET: a game that finishes is re-dealt at once
+ *              (episode+1, synthetic contract, Bot exchange); obs_out then
+ *              describes the new game and keeps TAROK_OBS_DONE set. */
+int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8_t *done_out,
+               uint64_t *obs_out, int flags, void *stream);
+
+/* Bot_igralec.igraj_karto (Igralec.py:158-159): uniform choice among the legal
+ * cards, drawn from the spec RNG (draw 128 + cards played).  action_out[g] = 255
+ * where nothing is to be played. */
+int tarok_policy_random(tarok_env *env, const uint64_t *obs, uint8_t *action_out, void *stream);
+
+/* tarok_policy_random + tarok_step fused in one launch; action_out may be NULL. */
+int tarok_step_random(tarok_env *env, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out,
+                      uint64_t *obs_out, int flags, void *stream);
+
+/* n_steps lock-steps of the random policy, launched from C (optionally as a
+ * replayed hipGraph of `graph_chunk` steps; 0 = eager launches).
+ * fused = 0: tarok_policy_random + tarok_step per step;  1: tarok_step_random.
+ * Buffers as in tarok_step (action [N] u8 scratch is required for fused = 0). */
+int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk, uint8_t *action,
+                     int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags,
+                     void *stream);
+
+/* Whole games in one launch (state never leaves registers): deal + setup + Bot
+ * exchange + random play to the end, for episode `episode` of every slot.
+ *   scores_out [N,4] i16, nsteps_out [N] i16 (cards played; Berac may stop early)
+ *   optional step-major traces, [48,N] each, padded with -1 / 0 / 255:
+ *   seats_out i8, masks_out u64, actions_out u8.
+ * Does not touch the env's stepping state. */
+int tarok_rollout_random(tarok_env *env, uint32_t episode, int16_t *scores_out, int16_t *nsteps_out,
+                         int8_t *seats_out, uint64_t *masks_out, uint8_t *actions_out, void *stream);
+
+/* Canonical state for parity checks / checkpoints: lanes_out [10,N] u64. */
+int tarok_get_state(tarok_env *env, uint64_t *lanes_out, void *stream);
+/* Per-slot bookkeeping: episode_out [N] u32 (current episode number),
+ * score_sum_out [N,4] i32 (scores summed over the slot's finished games =
+ * Tarok.rezultati per seat, Tarok.py:59-61).  Either may be NULL. */
+int tarok_get_counters(tarok_env *env, uint32_t *episode_out, int32_t *score_sum_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -62,6 +62,8 @@ def lib():
     vp = C.c_void_p
     L.to_rollout.restype = i64; L.to_rollout.argtypes = [u64, u64, i64, u64, i32, vp, vp, vp, vp, vp]
     L.to_rollout_mt.restype = i64; L.to_rollout_mt.argtypes = [i32, u64, u64, i64, u64, i32, vp, vp, vp, vp, vp]
+    L.to_obs_word.restype = u64; L.to_obs_word.argtypes = [P(ToGame), i32]
+    L.to_run_autoreset.restype = i64; L.to_run_autoreset.argtypes = [u64, u64, i64, i32, u32, i64, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -123,5 +125,15 @@ def rollout(seed, gidx0, n, episode, mix, threads=1, trace=True):
         return out[name].ctypes.data if name in out else None
     total = L.to_rollout_mt(threads, seed, gidx0, n, episode, mix, ptr("nsteps"), ptr("seats"),
                             ptr("masks"), ptr("actions"), ptr("scores"))
+    out["total_steps"] = int(total)
+    return out
+
+
+def run_autoreset(seed, gidx0, n, mix, n_steps, episode0=0):
+    """CPU statement of tarok_run_random(..., TAROK_AUTO_RESET)."""
+    out = dict(episode=np.zeros(n, np.uint32), score_sum=np.zeros((n, 4), np.int32),
+               lanes=np.zeros((10, n), np.uint64), obs=np.zeros(n, np.uint64))
+    total = lib().to_run_autoreset(seed, gidx0, n, mix, episode0, n_steps, out["episode"].ctypes.data,
+                                   out["score_sum"].ctypes.data, out["lanes"].ctypes.data, out["obs"].ctypes.data)
     out["total_steps"] = int(total)
     return out

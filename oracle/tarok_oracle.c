@@ -369,3 +369,50 @@ int64_t to_rollout_mt(int threads, uint64_t seed, uint64_t gidx0, int64_t n, uin
     for (int t = 0; t < used; t++) { pthread_join(th[t], NULL); total += jobs[t].total; }
     return total;
 }
+
+/* observation word of include/tarok_env.h (TAROK_OBS_*) for the seat to move */
+uint64_t to_obs_word(const to_game *g, int finished_now) {
+    uint64_t o = to_legal(g);
+    o |= (uint64_t)to_seat(g) << 54;
+    o |= (uint64_t)(g->trick_no * 4 + g->n_in_trick) << 56;
+    if (finished_now || g->phase == TO_PHASE_DONE) o |= 1ULL << 62;
+    o |= (uint64_t)g->error << 63;
+    return o;
+}
+
+/* n_steps lock-steps of the random policy with auto-reset (a finished game is
+ * replaced at once by episode+1 of the same slot), the CPU statement of
+ * tarok_run_random(..., TAROK_AUTO_RESET).  lanes_out is lane-major [10][n]. */
+int64_t to_run_autoreset(uint64_t seed, uint64_t gidx0, int64_t n, int mix, uint32_t episode0, int64_t n_steps,
+                         uint32_t *episode_out, int32_t *score_sum_out, uint64_t *lanes_out, uint64_t *obs_out) {
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) {
+        to_game g;
+        uint32_t ep = episode0;
+        int32_t sum[4] = {0, 0, 0, 0};
+        int fin = 0;
+        to_synth_game(&g, seed, gidx0 + (uint64_t)i, ep, mix);
+        uint64_t key = to_game_key(seed, gidx0 + (uint64_t)i, ep);
+        for (int64_t t = 0; t < n_steps; t++) {
+            int step = g.trick_no * 4 + g.n_in_trick;
+            int a = to_policy_action(key, step, to_legal(&g));
+            fin = to_step(&g, a) == 1;
+            total++;
+            if (fin) {
+                for (int s = 0; s < 4; s++) sum[s] += g.score[s];
+                ep++;
+                to_synth_game(&g, seed, gidx0 + (uint64_t)i, ep, mix);
+                key = to_game_key(seed, gidx0 + (uint64_t)i, ep);
+            }
+        }
+        if (episode_out) episode_out[i] = ep;
+        if (score_sum_out) for (int s = 0; s < 4; s++) score_sum_out[i * 4 + s] = sum[s];
+        if (lanes_out) {
+            uint64_t l[10];
+            to_export_lanes(&g, l);
+            for (int k = 0; k < 10; k++) lanes_out[(int64_t)k * n + i] = l[k];
+        }
+        if (obs_out) obs_out[i] = to_obs_word(&g, fin);
+    }
+    return total;
+}

@@ -1,0 +1,112 @@
+"""Build + ctypes binding of libtarokenv.so (include/tarok_env.h).
+
+The HIP library is the product: there is NO CPU fallback.  Anything that needs
+the environment raises if the shared library is missing or no GPU is visible."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "tarok_env.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "tarok_device.h"), os.path.join(HERE, "csrc", "deal_network.inc"),
+        os.path.join(ROOT, "include", "tarok_env.h")]
+LIB_PATH = os.path.join(HERE, "libtarokenv.so")
+ARCH = "gfx950"
+
+SYMBOLS = [
+    "tarok_strerror", "tarok_abi_version", "tarok_device_count", "tarok_last_hip_error",
+    "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_reset", "tarok_exchange",
+    "tarok_legal_actions", "tarok_step", "tarok_policy_random", "tarok_step_random",
+    "tarok_run_random", "tarok_rollout_random", "tarok_get_state", "tarok_get_counters",
+]
+
+
+class TarokNativeError(RuntimeError):
+    pass
+
+
+def hipcc_path():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if p and os.path.exists(p):
+            return p
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> tarok_amd/libtarokenv.so (in-tree)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def _check_single_hip_runtime():
+    """torch bundles its own libamdhip64 (same soname as /opt/rocm's).  The
+    loader shares it with us when torch is imported first; two runtimes in one
+    process would make torch's pointers/streams meaningless to our launches."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise TarokNativeError("two HIP runtimes are mapped (%s): import torch before tarok_amd" % sorted(paths))
+
+
+_lib = None
+
+
+def lib():
+    """Load libtarokenv.so (importing torch first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must precede the dlopen below)
+    if not os.path.exists(LIB_PATH):
+        raise TarokNativeError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    _check_single_hip_runtime()
+    vp, i32, i64, u64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
+    L.tarok_strerror.restype = C.c_char_p; L.tarok_strerror.argtypes = [i32]
+    L.tarok_abi_version.restype = i32; L.tarok_abi_version.argtypes = []
+    L.tarok_device_count.restype = i32; L.tarok_device_count.argtypes = []
+    L.tarok_last_hip_error.restype = i32; L.tarok_last_hip_error.argtypes = []
+    L.tarok_create.restype = i32; L.tarok_create.argtypes = [C.POINTER(vp), i32, i64, u64, u64, i32, i32]
+    L.tarok_destroy.restype = None; L.tarok_destroy.argtypes = [vp]
+    L.tarok_num_games.restype = i64; L.tarok_num_games.argtypes = [vp]
+    L.tarok_reset.restype = i32; L.tarok_reset.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.tarok_exchange.restype = i32; L.tarok_exchange.argtypes = [vp, vp, vp, vp]
+    L.tarok_legal_actions.restype = i32; L.tarok_legal_actions.argtypes = [vp, vp, vp, vp]
+    L.tarok_step.restype = i32; L.tarok_step.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.tarok_policy_random.restype = i32; L.tarok_policy_random.argtypes = [vp, vp, vp, vp]
+    L.tarok_step_random.restype = i32; L.tarok_step_random.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.tarok_run_random.restype = i32; L.tarok_run_random.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp]
+    L.tarok_rollout_random.restype = i32; L.tarok_rollout_random.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+    L.tarok_get_state.restype = i32; L.tarok_get_state.argtypes = [vp, vp, vp]
+    L.tarok_get_counters.restype = i32; L.tarok_get_counters.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        L = lib()
+        raise TarokNativeError("libtarokenv: %s (code %d, hipError %d)" % (
+            L.tarok_strerror(code).decode(), code, L.tarok_last_hip_error()))

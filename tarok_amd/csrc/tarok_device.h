@@ -1,0 +1,390 @@
+// Device-side Tarok rules on bit-packed per-game lanes (gfx950 / CDNA4 only).
+//
+// One game = 4 x uint64 ("packed lanes"), kept in two 16-byte SoA arrays so a
+// wave reads/writes 1 KiB contiguous per instruction:
+//
+//   L0 = A plane [53:0] | n_in_trick<<54 (2) | leader<<56 (2) | trick_no<<58 (4) | phase<<62 (2)
+//   L1 = B plane [53:0] | contract<<54 (4)   | declarer<<58 (2) | king<<60 (2)   | error<<62 (1)
+//   L2 = C plane [53:0] | team<<54 (4)       | tl<<58 (3)
+//   L3 = talon 6x6 bit ids [35:0] | current trick 4x6 bit ids [59:36]
+//
+// Card c (bit c of every plane) belongs to seat (B_c A_c).  C_c = 0: it is in
+// that seat's hand (Igralec.roka).  C_c = 1: it has left the hands — it lies in
+// that seat's won pile (Igralec.kupcek), or on the table (attributed to whoever
+// played it until the trick is resolved), or it is a talon card nobody owns yet
+// (seat bits 0; told apart through the ordered talon ids in L3).
+// `tl` is Klop's len(self.talon) (Klop.py:67) or, for Tri..Solo_ena, the chosen
+// talon group (7 = none yet).
+//
+// Reference rules cited per function; the CPU statement of the same rules is
+// oracle/tarok_oracle.c (test infrastructure, never linked here).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+#define TK_BIT(i) (1ULL << (i))
+#define TK_DECK ((1ULL << 54) - 1)
+#define TK_TAROK (((1ULL << 22) - 1) << 32)
+#define TK_PAGAT TK_BIT(32)
+// Roka.vrednost_stiha card values (Roka.py:76-95)
+#define TK_V5 (TK_BIT(7) | TK_BIT(15) | TK_BIT(23) | TK_BIT(31) | TK_BIT(32) | TK_BIT(52) | TK_BIT(53))
+#define TK_V4 (TK_BIT(6) | TK_BIT(14) | TK_BIT(22) | TK_BIT(30))
+#define TK_V3 (TK_BIT(5) | TK_BIT(13) | TK_BIT(21) | TK_BIT(29))
+#define TK_V2 (TK_BIT(4) | TK_BIT(12) | TK_BIT(20) | TK_BIT(28))
+// Roka.mozno_zalozit (Roka.py:23-27) with Karta.vrednost (Karta.py:10-16):
+// suit ranks 1..7 and taroks 2..7
+#define TK_DISCARDABLE (0x7F7F7F7FULL | (0x3FULL << 33))
+
+enum { TK_KLOP = 0, TK_TRI, TK_DVE, TK_ENA, TK_SOLO_TRI, TK_SOLO_DVE, TK_SOLO_ENA, TK_BERAC, TK_SOLO_BREZ, TK_ODPRTI_BERAC };
+enum { TK_PHASE_EXCHANGE = 1, TK_PHASE_PLAY = 2, TK_PHASE_DONE = 3 };
+
+struct Game {
+    u64 A, B, C, talon;
+    u32 trick, nt, leader, trick_no, phase, contract, declarer, king, error, team, tl;
+};
+
+__device__ __forceinline__ void unpack(Game &g, u64 l0, u64 l1, u64 l2, u64 l3) {
+    g.A = l0 & TK_DECK; g.B = l1 & TK_DECK; g.C = l2 & TK_DECK;
+    u32 m0 = (u32)(l0 >> 54), m1 = (u32)(l1 >> 54), m2 = (u32)(l2 >> 54);
+    g.nt = m0 & 3; g.leader = (m0 >> 2) & 3; g.trick_no = (m0 >> 4) & 15; g.phase = m0 >> 8;
+    g.contract = m1 & 15; g.declarer = (m1 >> 4) & 3; g.king = (m1 >> 6) & 3; g.error = (m1 >> 8) & 1;
+    g.team = m2 & 15; g.tl = (m2 >> 4) & 7;
+    g.talon = l3 & ((1ULL << 36) - 1);
+    g.trick = (u32)(l3 >> 36) & 0xFFFFFF;
+}
+
+__device__ __forceinline__ void pack(const Game &g, u64 &l0, u64 &l1, u64 &l2, u64 &l3) {
+    l0 = g.A | ((u64)(g.nt | (g.leader << 2) | (g.trick_no << 4) | (g.phase << 8)) << 54);
+    l1 = g.B | ((u64)(g.contract | (g.declarer << 4) | (g.king << 6) | (g.error << 8)) << 54);
+    l2 = g.C | ((u64)(g.team | (g.tl << 4)) << 54);
+    l3 = g.talon | ((u64)g.trick << 36);
+}
+
+__device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
+
+__device__ __forceinline__ u64 seat_cards(const Game &g, u32 s) {
+    u64 a = (s & 1) ? g.A : ~g.A, b = (s & 2) ? g.B : ~g.B;
+    return a & b & TK_DECK;
+}
+__device__ __forceinline__ u64 hand_of(const Game &g, u32 s) { return seat_cards(g, s) & ~g.C; }
+
+__device__ __forceinline__ u64 ids_mask(u64 ids, int first, int n) {
+    u64 m = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+        if (i >= first && i < first + n) m |= 1ULL << ((ids >> (6 * i)) & 63);
+    return m;
+}
+__device__ __forceinline__ u64 talon_all(const Game &g) { return ids_mask(g.talon, 0, 6); }
+
+__device__ __forceinline__ bool klop_family(u32 c) { return c == TK_KLOP || c == TK_BERAC || c == TK_ODPRTI_BERAC; }
+__device__ __forceinline__ bool has_exchange(u32 c) { return c >= TK_TRI && c <= TK_SOLO_ENA; }
+__device__ __forceinline__ bool has_king(u32 c) { return c >= TK_TRI && c <= TK_ENA; }
+// odpri_talon's korak (Navadna_igra.py:36-44) for Tri..Solo_ena: 3,2,1,3,2,1
+__device__ __forceinline__ u32 group_size(u32 c) { return 3 - ((c - 1) % 3); }
+
+// talon cards that sit in nobody's pile yet
+__device__ __forceinline__ u64 talon_unowned(const Game &g) {
+    if (g.contract == TK_KLOP) return ids_mask(g.talon, 0, (int)g.tl);
+    if (has_exchange(g.contract) && g.tl != 7) {
+        u32 gs = group_size(g.contract);
+        return talon_all(g) & ~ids_mask(g.talon, (int)(g.tl * gs), (int)gs);
+    }
+    return talon_all(g);
+}
+
+// Roka.prestej (Roka.py:56-98), order independent:
+// sum(val) - 2*floor(n/3) - [n%3 != 0]
+__device__ __forceinline__ int prestej(u64 m) {
+    int n = popc64(m);
+    int v = n + 4 * popc64(m & TK_V5) + 3 * popc64(m & TK_V4) + 2 * popc64(m & TK_V3) + popc64(m & TK_V2);
+    int q = n / 3;
+    return v - 2 * q - (n != 3 * q);
+}
+
+// mozne_karte: Navadna_igra.py:158-168; Klop.py:96-133 adds "pagat only when
+// nothing else is allowed" (the over-play filter there is dead code).
+__device__ __forceinline__ u64 legal_mask(u64 hand, bool has_lead, u32 lead, bool klopfam) {
+    u64 sm = lead >= 32 ? TK_TAROK : (0xFFULL << (8 * (lead >> 3)));
+    u64 s = hand & sm, t = hand & TK_TAROK;
+    u64 follow = s ? s : (t ? t : hand);
+    u64 b = has_lead ? follow : hand;
+    u64 nb = b & ~TK_PAGAT;
+    return (klopfam && nb) ? nb : b;
+}
+
+__device__ __forceinline__ u64 legal_now(const Game &g) {
+    u32 seat = (g.leader + g.nt) & 3;
+    return legal_mask(hand_of(g, seat), g.nt != 0, g.trick & 63, klop_family(g.contract));
+}
+
+// observation word (tarok_env.h TAROK_OBS_*)
+__device__ __forceinline__ u64 obs_word(const Game &g, bool finished_now) {
+    bool play = g.phase == TK_PHASE_PLAY;
+    u64 o = play ? legal_now(g) : 0;
+    o |= (u64)((g.leader + g.nt) & 3) << 54;
+    o |= (u64)(g.trick_no * 4 + g.nt) << 56;
+    if (finished_now || g.phase == TK_PHASE_DONE) o |= 1ULL << 62;
+    o |= (u64)g.error << 63;
+    return o;
+}
+
+__device__ __forceinline__ u64 pack_scores(int s0, int s1, int s2, int s3) {
+    return (u64)(uint16_t)(int16_t)s0 | ((u64)(uint16_t)(int16_t)s1 << 16) |
+           ((u64)(uint16_t)(int16_t)s2 << 32) | ((u64)(uint16_t)(int16_t)s3 << 48);
+}
+
+// Klop.start scoring (Klop.py:36-45): -points each; if anybody took more than
+// 35 everybody scores 0 (the -70 branch at Klop.py:39-40 is unreachable).
+__device__ __forceinline__ u64 score_klop(const Game &g) {
+    int c0 = prestej(seat_cards(g, 0) & g.C), c1 = prestej(seat_cards(g, 1) & g.C);
+    int c2 = prestej(seat_cards(g, 2) & g.C), c3 = prestej(seat_cards(g, 3) & g.C);
+    bool over = c0 > 35 || c1 > 35 || c2 > 35 || c3 > 35;
+    return over ? 0ULL : pack_scores(-c0, -c1, -c2, -c3);
+}
+
+// Navadna_igra.start scoring (Navadna_igra.py:80-113)
+__device__ __forceinline__ u64 score_navadna(const Game &g) {
+    u64 rest = talon_unowned(g);
+    u64 won = g.C & ~rest;
+    u64 t = 0;
+#pragma unroll
+    for (u32 s = 0; s < 4; s++)
+        if ((g.team >> s) & 1) t |= seat_cards(g, s) & won;
+    u64 kingbit = 1ULL << (g.king * 8 + 7);
+    bool alone_with_king = g.contract != TK_SOLO_BREZ && __popc(g.team) == 1 && has_king(g.contract) &&
+                           (seat_cards(g, g.declarer) & won & kingbit);   // Navadna_igra.py:87
+    if (alone_with_king) t |= rest;
+    int v = prestej(t), d = v - 35, ad = d < 0 ? -d : d;
+    int r = 5 * ((ad + 2) / 5);                                          // int(round(d/5))*5, :103
+    if (d < 0) r = -r;
+    int c = 10 * (int)g.contract;
+    int sc = (v > 35 ? c : -c) + r;
+    return pack_scores((g.team & 1) ? sc : 0, (g.team & 2) ? sc : 0, (g.team & 4) ? sc : 0, (g.team & 8) ? sc : 0);
+}
+
+// One card: the body of krog (Klop.py:47-79, Navadna_igra.py:115-141) after
+// igraj_karto returned card `a`, then the per-contract loop bookkeeping
+// (Klop.py:27-45, Berac.py:26-44, Navadna_igra.py:72-113).
+// Returns 0 = played, 1 = played and the game is finished (scores set),
+// -1 = not a legal card: nothing changes except the error bit.
+__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores) {
+    u64 legal = legal_now(g);
+    if (a >= 54 || !((legal >> a) & 1)) { g.error = 1; return -1; }
+    g.C |= 1ULL << a;
+    g.trick |= a << (6 * g.nt);
+    g.nt++;
+    if (g.nt < 4) return 0;
+    // pobere_stih / primerjaj_karti (Klop.py:81-94)
+    u32 c[4] = {g.trick & 63, (g.trick >> 6) & 63, (g.trick >> 12) & 63, (g.trick >> 18) & 63};
+    u32 w = 0, cw = c[0];
+#pragma unroll
+    for (u32 i = 1; i < 4; i++) {
+        u32 sw = min(cw >> 3, 4u), si = min(c[i] >> 3, 4u);
+        bool beats = (sw == si) ? (cw < c[i]) : (si == 4);
+        w = beats ? i : w;
+        cw = beats ? c[i] : cw;
+    }
+    u32 ws = (g.leader + w) & 3;
+    u64 tm = (1ULL << c[0]) | (1ULL << c[1]) | (1ULL << c[2]) | (1ULL << c[3]);
+    if (g.contract == TK_KLOP && g.tl > 0) {                              // talon gift, Klop.py:67-71
+        g.tl--;
+        tm |= 1ULL << ((g.talon >> (6 * g.tl)) & 63);
+    }
+    g.A = (g.A & ~tm) | ((ws & 1) ? tm : 0);
+    g.B = (g.B & ~tm) | ((ws & 2) ? tm : 0);
+    g.leader = ws; g.nt = 0; g.trick = 0; g.trick_no++;
+    if (g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC) {
+        int v = g.contract == TK_BERAC ? 70 : 90;
+        bool lost = ws == g.declarer;                                     // Berac.py:33-39
+        if (!lost && g.trick_no < 12) return 0;
+        int sc = lost ? -v : v;
+        u32 d = g.declarer;
+        scores = pack_scores(d == 0 ? sc : 0, d == 1 ? sc : 0, d == 2 ? sc : 0, d == 3 ? sc : 0);
+        g.phase = TK_PHASE_DONE;
+        return 1;
+    }
+    if (g.trick_no < 12) return 0;
+    scores = g.contract == TK_KLOP ? score_klop(g) : score_navadna(g);
+    g.phase = TK_PHASE_DONE;
+    return 1;
+}
+
+// Igra.razdeli's result + engine constructor (Igra.py:38-55,65-73;
+// Navadna_igra.py:20-30; Berac.py:15)
+__device__ __forceinline__ void setup_game(Game &g, u64 h0, u64 h1, u64 h2, u64 h3, u64 talon36,
+                                           u32 contract, u32 declarer, u32 king) {
+    g.A = h1 | h3; g.B = h2 | h3;
+    g.talon = talon36;
+    g.C = ids_mask(talon36, 0, 6);
+    g.trick = 0; g.nt = 0; g.trick_no = 0; g.error = 0;
+    g.contract = contract; g.declarer = declarer;
+    g.king = has_king(contract) ? king : 0;
+    g.leader = (contract == TK_BERAC || contract == TK_ODPRTI_BERAC) ? declarer : 0;
+    if (contract == TK_KLOP) {
+        g.team = 0; g.tl = 6;
+    } else {
+        u32 team = 1u << declarer;
+        if (has_king(contract)) {   // partner = holder of the called king BEFORE the exchange
+            u64 kb = 1ULL << (king * 8 + 7);
+            team |= (h0 & kb) ? 1u : 0u; team |= (h1 & kb) ? 2u : 0u;
+            team |= (h2 & kb) ? 4u : 0u; team |= (h3 & kb) ? 8u : 0u;
+        }
+        g.team = team;
+        g.tl = (has_exchange(contract) || contract == TK_SOLO_BREZ) ? 7 : 0;
+    }
+    g.phase = has_exchange(contract) ? TK_PHASE_EXCHANGE : TK_PHASE_PLAY;
+}
+
+// odpri_talon + menjaj_iz_talona (Navadna_igra.py:36-66, Igralec.py:161-171).
+// false = rejected (bad group, card not in hand, duplicate): error bit set.
+__device__ __forceinline__ bool apply_exchange(Game &g, u32 choice, u32 d0, u32 d1, u32 d2) {
+    u32 gs = group_size(g.contract);
+    if (choice >= 6 / gs) { g.error = 1; return false; }
+    u64 grp = ids_mask(g.talon, (int)(choice * gs), (int)gs);
+    u64 h = hand_of(g, g.declarer) | grp;
+    u32 d[3] = {d0, d1, d2};
+    u64 dm = 0;
+    bool ok = true;
+#pragma unroll
+    for (u32 i = 0; i < 3; i++)
+        if (i < gs) {
+            bool good = d[i] < 54 && ((h >> (d[i] & 63)) & 1) && !((dm >> (d[i] & 63)) & 1);
+            ok = ok && good;
+            dm |= good ? (1ULL << d[i]) : 0;
+        }
+    if (!ok) { g.error = 1; return false; }
+    u32 s = g.declarer;
+    g.A = (g.A & ~grp) | ((s & 1) ? grp : 0);
+    g.B = (g.B & ~grp) | ((s & 2) ? grp : 0);
+    g.C = (g.C & ~grp) | dm;
+    g.tl = choice;
+    g.phase = TK_PHASE_PLAY;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic inputs: counter-based RNG, deal, contract mix, Bot policy
+// (the build's own spec; CPU statement in oracle/tarok_spec.py)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ u64 game_key(u64 seed, u64 gidx, u64 episode) {
+    u64 a = gidx * 0x9E3779B97F4A7C15ULL + episode * 0xD1B54A32D192ED03ULL + 0x2545F4914F6CDD1DULL;
+    return mix64(seed ^ mix64(a));
+}
+__device__ __forceinline__ u32 rng32(u32 lo, u32 hi, u32 i) {
+    u32 x = lo ^ (i * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16; x ^= hi;
+    x *= 0x27D4EB2Fu; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ u32 rng32(u64 key, u32 i) { return rng32((u32)key, (u32)(key >> 32), i); }
+__device__ __forceinline__ u32 pick(u32 r, u32 n) { return __umulhi(r, n); }
+
+// index of the k-th (0-based) set bit, k < popcount(m): popcount bisection
+__device__ __forceinline__ u32 kth_bit(u64 m, u32 k) {
+    u32 w = (u32)m, base = 0, c = __popc(w);
+    if (k >= c) { k -= c; w = (u32)(m >> 32); base = 32; }
+    c = __popc(w & 0xFFFF); if (k >= c) { k -= c; w >>= 16; base += 16; }
+    c = __popc(w & 0xFF);   if (k >= c) { k -= c; w >>= 8;  base += 8; }
+    c = __popc(w & 0xF);    if (k >= c) { k -= c; w >>= 4;  base += 4; }
+    c = __popc(w & 0x3);    if (k >= c) { k -= c; w >>= 2;  base += 2; }
+    c = w & 1;              if (k >= c) { base += 1; }
+    return base;
+}
+
+// uniform card among the legal ones (Bot_igralec.igraj_karto, Igralec.py:158-159)
+__device__ __forceinline__ u32 policy_action(u64 key, u32 step, u64 mask) {
+    return kth_bit(mask, pick(rng32(key, 128 + step), (u32)popc64(mask)));
+}
+
+__device__ __forceinline__ void sample_setup(u64 key, int mix, u32 &contract, u32 &declarer, u32 &king) {
+    u32 c;
+    if (mix >= 16) c = (u32)(mix - 16);
+    else if (mix == 1) c = TK_TRI + pick(rng32(key, 65), 3);
+    else {
+        u32 fam = pick(rng32(key, 64), 3), r = rng32(key, 65);
+        u32 nav = pick(r, 7);
+        u32 navc = nav < 6 ? TK_TRI + nav : TK_SOLO_BREZ;   // Tri,Dve,Ena,Solo_tri,Solo_dve,Solo_ena,Solo_brez
+        c = fam == 0 ? TK_KLOP : (fam == 1 ? (pick(r, 2) == 0 ? TK_BERAC : TK_ODPRTI_BERAC) : navc);
+    }
+    contract = c;
+    declarer = c == TK_KLOP ? 0 : pick(rng32(key, 66), 4);
+    king = has_king(c) ? pick(rng32(key, 67), 4) : 0;
+}
+
+// Bot_igralec.menjaj_iz_talona (Igralec.py:161-171): group 0, random.sample of
+// the discardable cards (whole hand if there are too few: the reference raises)
+__device__ __forceinline__ void bot_exchange(Game &g, u64 key) {
+    u32 gs = group_size(g.contract);
+    u64 h = hand_of(g, g.declarer) | ids_mask(g.talon, 0, (int)gs);
+    u64 cand = h & TK_DISCARDABLE;
+    if ((u32)popc64(cand) < gs) cand = h;
+    u32 d[3] = {255, 255, 255};
+#pragma unroll
+    for (u32 j = 0; j < 3; j++)
+        if (j < gs) {
+            u32 c = kth_bit(cand, pick(rng32(key, 68 + j), (u32)popc64(cand)));
+            d[j] = c;
+            cand &= ~(1ULL << c);
+        }
+    apply_exchange(g, 0, d[0], d[1], d[2]);
+}
+
+// The deal: sort the 54 cards by (random key | card id); position p of the
+// sorted order is Igra.razdeli's karte[p] (Igra.py:65-73).
+// Per-thread form: 54 keys in registers through a fixed sorting network.
+__device__ __forceinline__ void deal_thread(u64 key, u64 &h0, u64 &h1, u64 &h2, u64 &h3, u64 &talon36) {
+    u32 a[54];
+    u32 lo = (u32)key, hi = (u32)(key >> 32);
+#pragma unroll
+    for (u32 c = 0; c < 54; c++) a[c] = (rng32(lo, hi, c) & 0xFFFFFFC0u) | c;
+#define CS(i, j) { u32 x_ = a[i], y_ = a[j]; a[i] = min(x_, y_); a[j] = max(x_, y_); }
+#include "deal_network.inc"
+#undef CS
+    u64 h[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 48; p++) h[p / 12] |= 1ULL << (a[p] & 63);
+    h0 = h[0]; h1 = h[1]; h2 = h[2]; h3 = h[3];
+    u64 t = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) t |= (u64)(a[48 + p] & 63) << (6 * p);
+    talon36 = t;
+}
+
+// Wave-cooperative form of the same deal for ONE game: lane c holds card c,
+// its position is its rank among the 54 keys (54 v_readlane broadcasts), the
+// hands fall out of four ballots whose bit index IS the card id.  Must be
+// called by all 64 lanes of the wave; klo/khi are wave-uniform.  Used where
+// only a few lanes of a wave need a new deal (auto-reset inside a step).
+__device__ __forceinline__ void deal_wave(u32 klo, u32 khi, u64 &h0, u64 &h1, u64 &h2, u64 &h3, u64 &talon36) {
+    u32 lane = __lane_id();
+    u32 key = lane < 54 ? ((rng32(klo, khi, lane) & 0xFFFFFFC0u) | lane) : 0xFFFFFFFFu;
+    u32 rank = 0;
+#pragma unroll
+    for (int j = 0; j < 54; j++) {
+        u32 kj = (u32)__builtin_amdgcn_readlane((int)key, j);
+        rank += kj < key ? 1u : 0u;
+    }
+    h0 = __ballot(rank < 12);
+    h1 = __ballot(rank >= 12 && rank < 24);
+    h2 = __ballot(rank >= 24 && rank < 36);
+    h3 = __ballot(rank >= 36 && rank < 48);
+    u64 t = 0;
+#pragma unroll
+    for (u32 p = 0; p < 6; p++) {
+        u64 b = __ballot(rank == 48 + p);
+        t |= (u64)__builtin_ctzll(b) << (6 * p);
+    }
+    talon36 = t;
+}

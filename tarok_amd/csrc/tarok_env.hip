@@ -1,0 +1,493 @@
+// libtarokenv: HIP kernels + C ABI (include/tarok_env.h).  gfx950 only.
+//
+// One thread per game, 256-thread workgroups (4 waves).  Per-game state is the
+// 4 packed uint64 lanes of tarok_device.h, stored as two 16-byte SoA arrays
+// (s01[g] = {L0,L1}, s23[g] = {L2,L3}): every wave-level load/store moves
+// 1 KiB contiguous.  The work is integer mask algebra + popcounts bounded by
+// HBM bandwidth (no MFMA); the only cross-lane work is the wave-cooperative
+// re-deal of the few games per wave that finish in a step.
+#include "tarok_device.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/tarok_env.h"
+
+#define TK_BLOCK 256
+
+struct tarok_env {
+    int device;
+    int64_t n;
+    u64 offset, seed;
+    int mix, flags;
+    ulonglong2 *s01, *s23;   // packed state
+    u64 *gkey;               // RNG key of the slot's current game
+    u32 *episode;            // episode number of the slot's current game
+    int4 *score_sum;         // scores summed over finished games, by seat
+    hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
+    // cached graph
+    hipGraphExec_t gexec;
+    int g_fused, g_chunk, g_flags;
+    void *g_action, *g_reward, *g_done, *g_obs;
+};
+
+static thread_local int g_last_hip = 0;
+
+#define HIPCHK(x)                                                   \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) { g_last_hip = (int)e_; return TAROK_EHIP; } \
+    } while (0)
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + TK_BLOCK - 1) / TK_BLOCK)); }
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_game(Game &g, const ulonglong2 *s01, const ulonglong2 *s23, int64_t i) {
+    ulonglong2 a = s01[i], b = s23[i];
+    unpack(g, a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void store_game(const Game &g, ulonglong2 *s01, ulonglong2 *s23, int64_t i) {
+    ulonglong2 a, b;
+    pack(g, a.x, a.y, b.x, b.y);
+    s01[i] = a; s23[i] = b;
+}
+
+// Igra.razdeli + engine construction + talon exchange for every slot.
+__global__ __launch_bounds__(TK_BLOCK) void k_reset(
+    int64_t n, u64 seed, u64 offset, u32 episode, int mix, int flags,
+    const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
+    const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, u64 *__restrict__ gkey,
+    u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 key = game_key(seed, offset + (u64)i, episode);
+    u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+    bool bad = false;
+    if (deals) {
+        const uint8_t *p = deals + i * 54;
+        u64 h[4] = {0, 0, 0, 0};
+        u64 seen = 0;
+        for (int k = 0; k < 48; k++) { u32 c = p[k]; bad |= c >= 54; c &= 63; seen |= 1ULL << c; h[k / 12] |= 1ULL << c; }
+        for (int k = 0; k < 6; k++) { u32 c = p[48 + k]; bad |= c >= 54; c &= 63; seen |= 1ULL << c; tal |= (u64)c << (6 * k); }
+        bad |= seen != TK_DECK;
+        h0 = h[0]; h1 = h[1]; h2 = h[2]; h3 = h[3];
+    } else {
+        deal_thread(key, h0, h1, h2, h3, tal);
+    }
+    u32 c, d, k;
+    if (contract) {
+        int ci = contract[i];
+        bad |= ci < 0 || ci > 9;
+        c = (u32)ci % 10u;
+        d = declarer ? ((u32)declarer[i] & 3u) : 0u;
+        k = king ? ((u32)king[i] & 3u) : 0u;
+    } else {
+        sample_setup(key, mix, c, d, k);
+    }
+    Game g;
+    setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+    if (g.phase == TK_PHASE_EXCHANGE && !(flags & TAROK_DEFER_EXCHANGE)) {
+        if (choice && discards) {
+            const uint8_t *q = discards + i * 3;
+            apply_exchange(g, (u32)(uint8_t)choice[i], q[0], q[1], q[2]);
+        } else {
+            bot_exchange(g, key);
+        }
+    }
+    if (bad) g.error = 1;
+    store_game(g, s01, s23, i);
+    gkey[i] = key;
+    ep[i] = episode;
+    if (flags & TAROK_CLEAR_COUNTERS) score_sum[i] = make_int4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_exchange(int64_t n, const int8_t *__restrict__ choice,
+                                                      const uint8_t *__restrict__ discards,
+                                                      ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23,
+                                                      const u64 *__restrict__ gkey) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Game g;
+    load_game(g, s01, s23, i);
+    if (g.phase != TK_PHASE_EXCHANGE) return;
+    if (choice && discards) {
+        const uint8_t *q = discards + i * 3;
+        apply_exchange(g, (u32)(uint8_t)choice[i], q[0], q[1], q[2]);
+    } else {
+        bot_exchange(g, gkey[i]);
+    }
+    store_game(g, s01, s23, i);
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_legal(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                   const ulonglong2 *__restrict__ s23, u64 *__restrict__ obs,
+                                                   int8_t *__restrict__ seat) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Game g;
+    load_game(g, s01, s23, i);
+    obs[i] = obs_word(g, false);
+    if (seat) seat[i] = (int8_t)((g.leader + g.nt) & 3);
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__restrict__ obs,
+                                                    const u64 *__restrict__ gkey, uint8_t *__restrict__ action) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 o = obs[i];
+    u64 m = o & TAROK_OBS_MASK;
+    u32 a = 255;
+    if (m) a = policy_action(gkey[i], (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m);
+    action[i] = (uint8_t)a;
+}
+
+// One lock-step of every game (one `next(g)` per game, Tarok.py:54).
+// RANDOM: the Bot policy is evaluated in the same launch instead of reading
+// `action`.  Every lane of a wave stays alive to the end: the auto-reset tail
+// is wave-cooperative.
+template <bool RANDOM>
+__global__ __launch_bounds__(TK_BLOCK) void k_step(
+    int64_t n, u64 seed, u64 offset, int mix, int flags,
+    const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
+    int16_t *__restrict__ reward, uint8_t *__restrict__ done, u64 *__restrict__ obs,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, u64 *__restrict__ gkey,
+    u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    bool valid = i < n;
+    int64_t ic = valid ? i : n - 1;
+    Game g;
+    load_game(g, s01, s23, ic);
+    u64 key = 0;
+    u32 a = 255;
+    bool play = valid && g.phase == TK_PHASE_PLAY;
+    if (RANDOM) {
+        key = gkey[ic];
+        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
+        if (action_out && valid) action_out[i] = (uint8_t)a;
+    } else {
+        a = action[ic];
+    }
+    u64 scores = 0;
+    int res = -2;
+    if (play) res = apply_step(g, a, scores);
+    bool fin = res == 1;
+    if (fin) {
+        if (reward) reinterpret_cast<u64 *>(reward)[i] = scores;
+        int4 acc = score_sum[i];
+        acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
+        acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
+        score_sum[i] = acc;
+    }
+    if (flags & TAROK_AUTO_RESET) {
+        u64 pend = __ballot(fin);
+        if (pend) {
+            u64 nkey = 0;
+            u32 nep = 0;
+            if (fin) { nep = ep[i] + 1; nkey = game_key(seed, offset + (u64)i, nep); }
+            u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+            u32 lane = __lane_id();
+            while (pend) {
+                int l = __builtin_ctzll(pend);
+                pend &= pend - 1;
+                u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)nkey, l);
+                u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(nkey >> 32), l);
+                u64 w0, w1, w2, w3, wt;
+                deal_wave(klo, khi, w0, w1, w2, w3, wt);
+                if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+            }
+            if (fin) {
+                u32 c, d, k;
+                sample_setup(nkey, mix, c, d, k);
+                setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+                if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, nkey);
+                ep[i] = nep;
+                gkey[i] = nkey;
+            }
+        }
+    }
+    if (valid) {
+        if (res != -2) store_game(g, s01, s23, i);
+        obs[i] = obs_word(g, fin);
+        if (done) done[i] = fin ? 1 : 0;
+    }
+}
+
+// Whole games in registers: deal, setup, Bot exchange, random play to the end.
+__global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 offset, u32 episode, int mix,
+                                                     int16_t *__restrict__ scores_out, int16_t *__restrict__ nsteps_out,
+                                                     int8_t *__restrict__ seats, u64 *__restrict__ masks,
+                                                     uint8_t *__restrict__ actions) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 key = game_key(seed, offset + (u64)i, episode);
+    u64 h0, h1, h2, h3, tal;
+    deal_thread(key, h0, h1, h2, h3, tal);
+    u32 c, d, k;
+    sample_setup(key, mix, c, d, k);
+    Game g;
+    setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+    if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
+    u64 scores = 0;
+    int t = 0, played = 0;
+    for (; t < 48; t++) {
+        bool live = g.phase == TK_PHASE_PLAY;
+        u64 m = 0;
+        u32 a = 255;
+        int seat = -1;
+        if (live) {
+            m = legal_now(g);
+            seat = (int)((g.leader + g.nt) & 3);
+            a = policy_action(key, (u32)t, m);
+            apply_step(g, a, scores);
+            played++;
+        }
+        if (seats) seats[(int64_t)t * n + i] = (int8_t)seat;
+        if (masks) masks[(int64_t)t * n + i] = m;
+        if (actions) actions[(int64_t)t * n + i] = (uint8_t)a;
+    }
+    if (scores_out) reinterpret_cast<u64 *>(scores_out)[i] = scores;
+    if (nsteps_out) nsteps_out[i] = (int16_t)played;
+}
+
+// canonical lanes for parity checks: H0-3, P0-3, TAL, META (tarok_env.h)
+__global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                       const ulonglong2 *__restrict__ s23, u64 *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Game g;
+    load_game(g, s01, s23, i);
+    u64 on_table = 0;
+    for (u32 j = 0; j < g.nt; j++) on_table |= 1ULL << ((g.trick >> (6 * j)) & 63);
+    u64 won = g.C & ~talon_unowned(g) & ~on_table;
+    for (u32 s = 0; s < 4; s++) {
+        out[(int64_t)s * n + i] = hand_of(g, s);
+        out[(int64_t)(4 + s) * n + i] = seat_cards(g, s) & won;
+    }
+    out[8 * n + i] = g.talon;
+    u64 m = g.trick;
+    m |= (u64)g.nt << 24;
+    m |= (u64)g.leader << 27;
+    m |= (u64)g.trick_no << 29;
+    m |= (u64)g.contract << 33;
+    m |= (u64)g.declarer << 37;
+    m |= (u64)(has_king(g.contract) ? g.king : 7) << 39;
+    m |= (u64)g.team << 42;
+    m |= (u64)(g.contract == TK_KLOP ? g.tl : 0) << 46;
+    m |= (u64)(has_exchange(g.contract) ? g.tl : 7) << 49;
+    m |= (u64)g.phase << 52;
+    m |= (u64)g.error << 54;
+    out[9 * n + i] = m;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *tarok_strerror(int code) {
+    switch (code) {
+        case TAROK_OK: return "ok";
+        case TAROK_EINVAL: return "invalid argument";
+        case TAROK_EHIP: return "HIP runtime error (see tarok_last_hip_error)";
+        case TAROK_ENOMEM: return "out of device memory";
+        case TAROK_ENODEV: return "no usable GPU";
+        default: return "unknown error";
+    }
+}
+
+int tarok_abi_version(void) { return TAROK_ABI_VERSION; }
+int tarok_last_hip_error(void) { return g_last_hip; }
+
+int tarok_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_offset, uint64_t seed, int mix, int flags) {
+    if (!out || n_games <= 0 || n_games > (1LL << 31)) return TAROK_EINVAL;
+    if (!(mix == TAROK_MIX_ALL || mix == TAROK_MIX_NAVADNA3 || (mix >= TAROK_MIX_FIXED && mix < TAROK_MIX_FIXED + 10))) return TAROK_EINVAL;
+    if (device < 0 || device >= tarok_device_count()) return TAROK_ENODEV;
+    HIPCHK(hipSetDevice(device));
+    tarok_env *e = new tarok_env();
+    memset(e, 0, sizeof *e);
+    e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
+    hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->episode, (size_t)n_games * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->score_sum, (size_t)n_games * sizeof(int4));
+    if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMemset(e->gkey, 0, (size_t)n_games * sizeof(u64));
+    if (r == hipSuccess) r = hipMemset(e->episode, 0, (size_t)n_games * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->score_sum, 0, (size_t)n_games * sizeof(int4));
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking);
+    if (r != hipSuccess) {
+        g_last_hip = (int)r;
+        tarok_destroy(e);
+        return r == hipErrorOutOfMemory ? TAROK_ENOMEM : TAROK_EHIP;
+    }
+    *out = e;
+    return TAROK_OK;
+}
+
+void tarok_destroy(tarok_env *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->gkey);
+    (void)hipFree(e->episode); (void)hipFree(e->score_sum);
+    delete e;
+}
+
+int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
+
+int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8_t *contract, const int8_t *declarer,
+                const int8_t *king_suit, const int8_t *talon_choice, const uint8_t *discards, int flags, void *stream) {
+    if (!e) return TAROK_EINVAL;
+    if ((talon_choice == nullptr) != (discards == nullptr)) return TAROK_EINVAL;
+    if (contract && !declarer) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_reset, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
+                       episode, e->mix, flags, deals, contract, declarer, king_suit, talon_choice, discards, e->s01,
+                       e->s23, e->gkey, e->episode, e->score_sum);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_exchange(tarok_env *e, const int8_t *talon_choice, const uint8_t *discards, void *stream) {
+    if (!e || (talon_choice == nullptr) != (discards == nullptr)) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_exchange, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, talon_choice,
+                       discards, e->s01, e->s23, e->gkey);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_legal_actions(tarok_env *e, uint64_t *obs_out, int8_t *seat_out, void *stream) {
+    if (!e || !obs_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_legal, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23,
+                       (u64 *)obs_out, seat_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+static inline void launch_step(tarok_env *e, bool random, const uint8_t *action, uint8_t *action_out,
+                               int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s) {
+    if (random)
+        hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->gkey, e->episode,
+                           e->score_sum);
+    else
+        hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->gkey, e->episode,
+                           e->score_sum);
+}
+
+int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
+               int flags, void *stream) {
+    if (!e || !action || !obs_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    launch_step(e, false, action, nullptr, reward_out, done_out, obs_out, flags, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_policy_random(tarok_env *e, const uint64_t *obs, uint8_t *action_out, void *stream) {
+    if (!e || !obs || !action_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const u64 *)obs,
+                       e->gkey, action_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
+                      int flags, void *stream) {
+    if (!e || !obs_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    launch_step(e, true, nullptr, action_out, reward_out, done_out, obs_out, flags, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+static inline void launch_one(tarok_env *e, int fused, uint8_t *action, int16_t *reward, uint8_t *done,
+                              uint64_t *obs, int flags, hipStream_t s) {
+    if (fused) {
+        launch_step(e, true, nullptr, nullptr, reward, done, obs, flags, s);
+    } else {
+        hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, (const u64 *)obs, e->gkey, action);
+        launch_step(e, false, action, nullptr, reward, done, obs, flags, s);
+    }
+}
+
+int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, uint8_t *action, int16_t *reward_out,
+                     uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
+    if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 4096) return TAROK_EINVAL;
+    if (!fused && !action) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    int64_t left = n_steps;
+    if (graph_chunk > 0 && left >= graph_chunk) {
+        bool hit = e->gexec && e->g_fused == fused && e->g_chunk == graph_chunk && e->g_flags == flags &&
+                   e->g_action == action && e->g_reward == reward_out && e->g_done == done_out && e->g_obs == obs_out;
+        if (!hit) {
+            if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
+            for (int k = 0; k < graph_chunk; k++)
+                launch_one(e, fused, action, reward_out, done_out, obs_out, flags, e->cap_stream);
+            HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
+            hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
+            e->g_fused = fused; e->g_chunk = graph_chunk; e->g_flags = flags;
+            e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
+        }
+        while (left >= graph_chunk) {
+            HIPCHK(hipGraphLaunch(e->gexec, s));
+            left -= graph_chunk;
+        }
+    }
+    for (; left > 0; left--) launch_one(e, fused, action, reward_out, done_out, obs_out, flags, s);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_rollout_random(tarok_env *e, uint32_t episode, int16_t *scores_out, int16_t *nsteps_out, int8_t *seats_out,
+                         uint64_t *masks_out, uint8_t *actions_out, void *stream) {
+    if (!e) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_rollout, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
+                       episode, e->mix, scores_out, nsteps_out, seats_out, (u64 *)masks_out, actions_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_get_state(tarok_env *e, uint64_t *lanes_out, void *stream) {
+    if (!e || !lanes_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_get_state, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23,
+                       (u64 *)lanes_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_get_counters(tarok_env *e, uint32_t *episode_out, int32_t *score_sum_out, void *stream) {
+    if (!e) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    if (episode_out)
+        HIPCHK(hipMemcpyAsync(episode_out, e->episode, (size_t)e->n * sizeof(u32), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (score_sum_out)
+        HIPCHK(hipMemcpyAsync(score_sum_out, e->score_sum, (size_t)e->n * sizeof(int4), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TAROK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+"""TarokVecEnv — N lock-stepped 4-player Tarok games on one MI355X.
+
+Host-side mirror of what the reference does with N `Igra` objects inside
+`Tarok.paralel_start` (Tarok.py:30-62): `reset()` deals and sets the contracts
+up (Igra.razdeli + engine constructors + talon exchange), `legal_actions()` is
+`mozne_karte` for the seat to move, `step()` is one `next(g)` per game.  All
+compute is in libtarokenv.so (HIP, gfx950); torch only provides device memory
+and streams.  There is no CPU path: constructing an env without the library or
+without a GPU raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native
+from . import karte as K
+
+
+def _u64(t):
+    """int64 torch tensor -> numpy uint64 (host)."""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+class Obs:
+    """Per-game observation words (include/tarok_env.h TAROK_OBS_*) as an int64
+    device tensor with decoded views."""
+
+    def __init__(self, words):
+        self.words = words
+
+    @property
+    def mask(self):            # legal-card mask of the seat to move (= `mozne`)
+        return self.words & K.OBS_MASK
+
+    @property
+    def seat(self):
+        return (self.words >> K.OBS_SEAT_SHIFT) & 3
+
+    @property
+    def step(self):            # cards played so far in the game
+        return (self.words >> K.OBS_STEP_SHIFT) & 63
+
+    @property
+    def done(self):
+        return ((self.words >> K.OBS_DONE_BIT) & 1).bool()
+
+    @property
+    def error(self):
+        return self.words < 0   # bit 63
+
+    def mask_numpy(self):
+        return _u64(self.mask)
+
+
+class TarokVecEnv:
+    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0):
+        self._h = None
+        L = _native.lib()
+        if not torch.cuda.is_available() or L.tarok_device_count() == 0:
+            raise _native.TarokNativeError("TarokVecEnv needs an MI355X: no GPU is visible and there is no CPU fallback")
+        self.L = L
+        self.n = int(n_games)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.seed, self.mix, self.game_offset = int(seed), int(mix), int(game_offset)
+        h = C.c_void_p()
+        _native.check(L.tarok_create(C.byref(h), self.device_index, self.n, self.game_offset, self.seed, self.mix, 0))
+        self._h = h
+        with torch.cuda.device(self.device):
+            self.obs_words = torch.zeros(self.n, dtype=torch.int64, device=self.device)
+            self.reward = torch.zeros((self.n, 4), dtype=torch.int16, device=self.device)
+            self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self.action = torch.full((self.n,), 255, dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if self._h is not None:
+            torch.cuda.synchronize(self.device)
+            self.L.tarok_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype, shape):
+        """None -> NULL; tensor / array -> contiguous device tensor of dtype."""
+        if x is None:
+            return None
+        t = torch.as_tensor(x)
+        t = t.to(device=self.device, dtype=dtype).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------
+    def reset(self, episode=0, deals=None, contract=None, declarer=None, king_suit=None,
+              talon_choice=None, discards=None, defer_exchange=False, clear_counters=True):
+        """Deal + set up all N games (Igra.py:38-55,65-73; Navadna_igra.py:20-68).
+        Returns the first observation."""
+        n = self.n
+        deals = self._dev(deals, torch.uint8, (n, 54))
+        contract = self._dev(contract, torch.int8, (n,))
+        declarer = self._dev(declarer, torch.int8, (n,))
+        king_suit = self._dev(king_suit, torch.int8, (n,))
+        talon_choice = self._dev(talon_choice, torch.int8, (n,))
+        discards = self._dev(discards, torch.uint8, (n, 3))
+        flags = (K.DEFER_EXCHANGE if defer_exchange else 0) | (K.CLEAR_COUNTERS if clear_counters else 0)
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_reset(self._h, int(episode), self._p(deals), self._p(contract), self._p(declarer),
+                                             self._p(king_suit), self._p(talon_choice), self._p(discards), flags,
+                                             self._stream()))
+        return self.legal_actions()
+
+    def exchange(self, talon_choice=None, discards=None):
+        """menjaj_iz_talona for games still waiting (Navadna_igra.py:60-66)."""
+        talon_choice = self._dev(talon_choice, torch.int8, (self.n,))
+        discards = self._dev(discards, torch.uint8, (self.n, 3))
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_exchange(self._h, self._p(talon_choice), self._p(discards), self._stream()))
+        return self.legal_actions()
+
+    def legal_actions(self):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_legal_actions(self._h, self._p(self.obs_words), None, self._stream()))
+        return Obs(self.obs_words)
+
+    def step(self, action, auto_reset=False):
+        """One card per game.  Returns (Obs, reward[N,4] i16 — valid where done, done[N] u8)."""
+        a = self._dev(action, torch.uint8, (self.n,))
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_step(self._h, self._p(a), self._p(self.reward), self._p(self.done),
+                                            self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0, self._stream()))
+        return Obs(self.obs_words), self.reward, self.done
+
+    def policy_random(self, obs=None):
+        """Bot_igralec.igraj_karto on device (Igralec.py:158-159)."""
+        words = self.obs_words if obs is None else obs.words
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_policy_random(self._h, self._p(words), self._p(self.action), self._stream()))
+        return self.action
+
+    def step_random(self, auto_reset=False):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_step_random(self._h, self._p(self.action), self._p(self.reward), self._p(self.done),
+                                                   self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
+                                                   self._stream()))
+        return Obs(self.obs_words), self.reward, self.done
+
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True):
+        """n_steps lock-steps of the random policy launched from C (optionally graph-replayed)."""
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_run_random(self._h, int(n_steps), 1 if fused else 0, int(graph_chunk),
+                                                  self._p(self.action), self._p(self.reward), self._p(self.done),
+                                                  self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
+                                                  self._stream()))
+
+    def rollout_random(self, episode=0, trace=False):
+        """Whole random-policy games in one launch.  Returns dict of device tensors:
+        scores [N,4] i16, nsteps [N] i16 and, with trace, step-major seats/masks/actions [48,N]."""
+        n = self.n
+        with torch.cuda.device(self.device):
+            out = dict(scores=torch.empty((n, 4), dtype=torch.int16, device=self.device),
+                       nsteps=torch.empty(n, dtype=torch.int16, device=self.device))
+            if trace:
+                out["seats"] = torch.empty((48, n), dtype=torch.int8, device=self.device)
+                out["masks"] = torch.empty((48, n), dtype=torch.int64, device=self.device)
+                out["actions"] = torch.empty((48, n), dtype=torch.uint8, device=self.device)
+            _native.check(self.L.tarok_rollout_random(self._h, int(episode), self._p(out["scores"]), self._p(out["nsteps"]),
+                                                      self._p(out.get("seats")), self._p(out.get("masks")),
+                                                      self._p(out.get("actions")), self._stream()))
+        return out
+
+    def state(self):
+        """Canonical lanes [10,N] (H0-3, P0-3, TAL, META) as host numpy uint64."""
+        with torch.cuda.device(self.device):
+            lanes = torch.empty((10, self.n), dtype=torch.int64, device=self.device)
+            _native.check(self.L.tarok_get_state(self._h, self._p(lanes), self._stream()))
+        return _u64(lanes)
+
+    def counters(self):
+        """(episode[N] int64, score_sum[N,4] int32) host numpy."""
+        with torch.cuda.device(self.device):
+            ep = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            ss = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            _native.check(self.L.tarok_get_counters(self._h, self._p(ep), self._p(ss), self._stream()))
+        return ep.cpu().numpy().astype(np.int64), ss.cpu().numpy()

@@ -1,0 +1,79 @@
+"""Card / contract vocabulary of the reference (Karta.py, Tip_igre.py) as plain ints.
+
+card id = suit*8 + rank-1 for suits KARA=0, SRCE=1, PIK=2, KRIZ=3 (rank 1..8, 8 = king);
+taroks: id = 32 + n-1 for n = 1..22 (Karta.v_id, Karta.py:19-23).
+contract code = int(Tip_igre) // 10 (Tip_igre.py:4-15).
+"""
+import enum
+
+
+class Barva(enum.IntEnum):          # Karta.py:69-74
+    KARA = 0
+    SRCE = 1
+    PIK = 2
+    KRIZ = 3
+    TAROK = 4
+
+
+class Tip(enum.IntEnum):            # Tip_igre.py:4-15, value = int(Tip_igre)//10
+    Klop = 0
+    Tri = 1
+    Dve = 2
+    Ena = 3
+    Solo_tri = 4
+    Solo_dve = 5
+    Solo_ena = 6
+    Berac = 7
+    Solo_brez = 8
+    Odprti_berac = 9
+
+
+DECK = (1 << 54) - 1
+PAGAT, MOND, SKIS = 32, 52, 53
+
+# synthetic contract mixes (include/tarok_env.h TAROK_MIX_*)
+MIX_ALL = 0
+MIX_NAVADNA3 = 1
+MIX_FIXED = 16
+
+# flags (include/tarok_env.h)
+DEFER_EXCHANGE = 1
+AUTO_RESET = 2
+CLEAR_COUNTERS = 4
+
+# observation word
+OBS_MASK = DECK
+OBS_SEAT_SHIFT = 54
+OBS_STEP_SHIFT = 56
+OBS_DONE_BIT = 62
+OBS_ERROR_BIT = 63
+
+PHASE_EXCHANGE, PHASE_PLAY, PHASE_DONE = 1, 2, 3
+
+
+def card_id(barva, st):
+    """Karta(barva, st).v_id()  (Karta.py:19-23)"""
+    return 32 + st - 1 if int(barva) == 4 else int(barva) * 8 + st - 1
+
+
+def card_from_id(cid):
+    """Karta.iz_id (Karta.py:32-47) -> (barva, st)"""
+    return (Barva.TAROK, cid - 31) if cid > 31 else (Barva(cid // 8), cid % 8 + 1)
+
+
+def card_name(cid):
+    """str(Karta) (Karta.py:52-57)"""
+    b, st = card_from_id(cid)
+    m = {5: "J", 6: "K", 7: "D", 8: "KR"}[st] if b != Barva.TAROK and st > 4 else st
+    return "%s_%s" % (b.name, m)
+
+
+def mask_to_ids(mask):
+    return [i for i in range(54) if (int(mask) >> i) & 1]
+
+
+def ids_to_mask(ids):
+    m = 0
+    for i in ids:
+        m |= 1 << int(i)
+    return m

@@ -1,0 +1,59 @@
+"""One process per GPU: which slice of the global game indices a rank owns, and the
+(tiny) host-side reductions.  Games are independent (Tarok.py:33-35 builds N separate
+Igra objects; only the score sum at Tarok.py:59-61 combines them), so the env path
+needs NO collective: the deal RNG is keyed by the GLOBAL game index, each rank plays
+`game_offset .. game_offset+n_local` and the totals are summed once at the end."""
+import os
+
+
+def world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def weak_shard(n_per_gpu, rank):
+    """Weak scaling (BASELINE config 5: 8 x 65,536): every rank holds n_per_gpu games."""
+    return rank * n_per_gpu, n_per_gpu
+
+
+def strong_shard(n_total, rank, world_size):
+    """Contiguous split of n_total games; the first n_total % world ranks get one more."""
+    base, extra = divmod(n_total, world_size)
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def init_process_group(backend=None):
+    """nccl (= RCCL) when a GPU is visible, gloo otherwise; rendezvous on 127.0.0.1."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, rank=world()[0], world_size=world()[2])
+
+
+def sum_over_ranks(t):
+    """In-place SUM all-reduce of a small tensor (score totals, step counts)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def max_over_ranks(t):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

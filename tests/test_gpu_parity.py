@@ -1,0 +1,277 @@
+"""GPU parity: the HIP path (through the C ABI, via tarok_amd.TarokVecEnv) against
+the CPU oracle and against the fixtures produced by running the reference.
+Bit-exact: every legal mask, seat, action, score, pile and state lane.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import tarok_amd
+    from tarok_amd import _native
+    assert os.path.exists(_native.LIB_PATH), "libtarokenv.so missing: the HIP path is the product, no fallback"
+    return tarok_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def S():
+    from oracle import tarok_spec
+    return tarok_spec
+
+
+@pytest.fixture(scope="module")
+def traces(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "traces_v1.npz")))
+
+
+def digest(p):
+    h = hashlib.sha256()
+    for name in ("nsteps", "seats", "masks", "actions", "scores"):
+        h.update(np.ascontiguousarray(p[name]).tobytes())
+    return h.hexdigest()
+
+
+def oracle_games(O, S, tr, idx):
+    games = []
+    for i in idx:
+        g = O.Game(tr["deals"][i], tr["contract"][i], tr["declarer"][i], tr["king"][i])
+        if g.g.phase == 1:
+            assert g.exchange(tr["choice"][i], tr["discards"][i][: S.N_DISCARD[int(tr["contract"][i])]]) == 0
+        games.append(g)
+    return games
+
+
+def test_golden_traces_every_step(T, O, S, traces):
+    """All 2880 reference traces replayed on the GPU: masks/seats per step, done,
+    scores, final piles/hands vs the reference; full canonical state vs the oracle."""
+    tr = traces
+    n = len(tr["contract"])
+    env = T.TarokVecEnv(n, seed=0, mix=T.karte.MIX_ALL)
+    king = np.where(tr["king"] < 0, 0, tr["king"]).astype(np.int8)
+    choice = np.where(tr["choice"] < 0, 0, tr["choice"]).astype(np.int8)
+    obs = env.reset(deals=tr["deals"], contract=tr["contract"], declarer=tr["declarer"], king_suit=king,
+                    talon_choice=choice, discards=tr["discards"])
+    sub = list(range(0, n, 7))
+    og = oracle_games(O, S, tr, sub)
+    st = env.state()
+    for j, i in enumerate(sub):
+        assert (st[:, i] == og[j].lanes()).all(), ("state after reset", i, int(tr["contract"][i]))
+    scores = np.zeros((n, 4), np.int16)
+    finished = np.zeros(n, bool)
+    for t in range(48):
+        live = tr["nsteps"] > t
+        m = obs.mask_numpy()
+        assert (m[live] == tr["masks"][live, t]).all(), t
+        assert (m[~live] == 0).all()
+        assert (obs.seat.cpu().numpy()[live] == tr["seats"][live, t]).all(), t
+        assert (obs.step.cpu().numpy()[live] == t).all()
+        assert not obs.error.any().item()
+        obs, reward, done = env.step(tr["actions"][:, t])
+        d = done.cpu().numpy().astype(bool)
+        assert (d == (tr["nsteps"] == t + 1)).all(), t
+        scores[d] = reward.cpu().numpy()[d]
+        finished |= d
+        assert (obs.done.cpu().numpy() == finished).all()
+        st = env.state()
+        for j, i in enumerate(sub):
+            if tr["nsteps"][i] > t:
+                og[j].step(tr["actions"][i, t])
+            assert (st[:, i] == og[j].lanes()).all(), ("state", i, t, int(tr["contract"][i]))
+    assert finished.all()
+    assert (scores == tr["scores"]).all()
+    st = env.state()
+    assert (st[0:4].T == tr["hands_end"]).all()
+    assert (st[4:8].T == tr["piles"]).all()
+    env.close()
+
+
+def test_device_deal_and_setup_match_oracle(T, O, S):
+    """reset() with no arrays: sorting-network deal + contract mix + Bot exchange."""
+    for mix, n, seed, ep in [(S.MIX_ALL, 4096, 3, 0), (S.MIX_NAVADNA3, 1000, 4, 9), (S.MIX_FIXED + S.SOLO_DVE, 300, 5, 2)]:
+        env = T.TarokVecEnv(n, seed=seed, mix=mix, game_offset=17)
+        env.reset(episode=ep)
+        st = env.state()
+        for i in range(n):
+            g = O.Game.synth(seed, 17 + i, ep, mix)
+            assert (st[:, i] == g.lanes()).all(), (mix, i)
+        env.close()
+
+
+def test_deferred_exchange_flow(T, O, S, traces):
+    """reset(defer) -> exchange(): the two-phase form of Navadna_igra.py:60-66."""
+    tr = traces
+    idx = np.where((tr["contract"] >= 1) & (tr["contract"] <= 6))[0][:512]
+    n = len(idx)
+    env = T.TarokVecEnv(n, seed=0)
+    king = np.where(tr["king"][idx] < 0, 0, tr["king"][idx]).astype(np.int8)
+    obs = env.reset(deals=tr["deals"][idx], contract=tr["contract"][idx], declarer=tr["declarer"][idx],
+                    king_suit=king, defer_exchange=True)
+    assert (obs.mask_numpy() == 0).all()
+    st = env.state()
+    for j, i in enumerate(idx[:64]):
+        g = O.Game(tr["deals"][i], tr["contract"][i], tr["declarer"][i], tr["king"][i])
+        assert g.g.phase == 1 and (st[:, j] == g.lanes()).all()
+    obs = env.exchange(talon_choice=tr["choice"][idx], discards=tr["discards"][idx])
+    assert (obs.mask_numpy() == tr["masks"][idx, 0]).all()
+    # bad exchange: discard a card that is not in the hand -> error bit, still waiting
+    env.reset(deals=tr["deals"][idx], contract=tr["contract"][idx], declarer=tr["declarer"][idx],
+              king_suit=king, defer_exchange=True)
+    bad = tr["discards"][idx].copy()
+    other = (tr["declarer"][idx].astype(int) + 1) % 4
+    bad[:, 0] = tr["deals"][idx][np.arange(n), other * 12]     # a card of another seat's hand
+    obs = env.exchange(talon_choice=np.zeros(n, np.int8), discards=bad)
+    assert obs.error.all().item() and (obs.mask_numpy() == 0).all()
+    env.close()
+
+
+def test_illegal_action_rejected(T, S):
+    n = 512
+    env = T.TarokVecEnv(n, seed=9, mix=S.MIX_ALL)
+    obs = env.reset()
+    before = env.state()
+    m = obs.mask_numpy()
+    bad = np.array([[i for i in range(54) if not (int(x) >> i) & 1][0] for x in m], np.uint8)
+    bad[::3] = 200                                  # out of range ids too
+    obs, reward, done = env.step(bad)
+    assert obs.error.all().item()
+    assert (obs.mask_numpy() == m).all() and not done.any().item()
+    after = env.state()
+    assert (before[:9] == after[:9]).all()
+    assert ((after[9] >> np.uint64(54)) & np.uint64(1)).all()
+    assert ((after[9] & ~(np.uint64(1) << np.uint64(54))) == before[9]).all()
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 100, 257])
+def test_ragged_sizes(T, O, S, n):
+    env = T.TarokVecEnv(n, seed=21, mix=S.MIX_ALL)
+    out = env.rollout_random(episode=1, trace=True)
+    ref = O.rollout(21, 0, n, 1, S.MIX_ALL)
+    assert (out["scores"].cpu().numpy() == ref["scores"]).all()
+    assert (out["nsteps"].cpu().numpy() == ref["nsteps"]).all()
+    obs = env.reset(episode=1)
+    for t in range(48):
+        a = env.policy_random(obs)
+        obs, _, _ = env.step(a, auto_reset=True)
+    ar = O.run_autoreset(21, 0, n, S.MIX_ALL, 48, episode0=1)
+    assert (env.state() == ar["lanes"]).all()
+    env.close()
+
+
+def gpu_rollout_arrays(env, episode):
+    out = env.rollout_random(episode=episode, trace=True)
+    return dict(nsteps=out["nsteps"].cpu().numpy(), scores=out["scores"].cpu().numpy(),
+                seats=np.ascontiguousarray(out["seats"].cpu().numpy().T),
+                masks=np.ascontiguousarray(out["masks"].cpu().numpy().T).view(np.uint64),
+                actions=np.ascontiguousarray(out["actions"].cpu().numpy().T))
+
+
+def test_fused_rollout_digests_match_reference(T, golden_dir):
+    """BASELINE configs 2 and 3 at full size: the fused rollout kernel's
+    masks/seats/actions/scores hash to the digest of the REFERENCE engine's run."""
+    with open(os.path.join(golden_dir, "digests_v1.json")) as f:
+        runs = json.load(f)["synthetic"]
+    for r in runs:
+        env = T.TarokVecEnv(r["n"], seed=r["seed"], mix=r["mix"])
+        got = gpu_rollout_arrays(env, r["episode"])
+        assert int(got["nsteps"].sum()) == r["total_steps"], r["name"]
+        assert digest(got) == r["sha256"], r["name"]
+        env.close()
+
+
+def test_step_api_full_size_vs_oracle(T, O, S):
+    """65,536 mixed games through reset / policy kernel / step kernel, every step
+    compared with the oracle's trace (which is digest-pinned to the reference)."""
+    n, seed = 65536, 0
+    ref = O.rollout(seed, 0, n, 0, S.MIX_ALL, threads=8)
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    obs = env.reset()
+    scores = np.zeros((n, 4), np.int16)
+    nsteps = np.zeros(n, np.int16)
+    for t in range(48):
+        live = ref["nsteps"] > t
+        assert (obs.mask_numpy() == ref["masks"][:, t]).all(), t
+        assert (obs.seat.cpu().numpy()[live] == ref["seats"][live, t]).all(), t
+        a = env.policy_random(obs)
+        assert (a.cpu().numpy() == ref["actions"][:, t]).all(), t
+        obs, reward, done = env.step(a)
+        d = done.cpu().numpy().astype(bool)
+        scores[d] = reward.cpu().numpy()[d]
+        nsteps[d] = t + 1
+    assert (nsteps == ref["nsteps"]).all() and (scores == ref["scores"]).all()
+    ep, ss = env.counters()
+    assert (ss == ref["scores"]).all() and (ep == 0).all()
+    # size-independent properties of the scores (Klop.py:36-45, Berac.py:16-18, Navadna_igra.py:100-108)
+    st = env.state()
+    contract = ((st[9] >> np.uint64(33)) & np.uint64(15)).astype(int)
+    sc = scores.astype(int)
+    klop = sc[contract == 0]
+    assert ((klop <= 0).all(axis=1)).all() and (klop >= -35).all()
+    assert set(np.unique(np.abs(sc[contract == 7]))) <= {0, 70} and set(np.unique(np.abs(sc[contract == 9]))) <= {0, 90}
+    nav = sc[(contract >= 1) & (contract <= 6) | (contract == 8)]
+    assert (nav % 5 == 0).all() and ((nav != 0).sum(axis=1) <= 2).all()
+    env.close()
+
+
+def test_fused_step_equals_two_kernel_path(T, S):
+    n = 8192
+    a = T.TarokVecEnv(n, seed=5, mix=S.MIX_ALL)
+    b = T.TarokVecEnv(n, seed=5, mix=S.MIX_ALL)
+    oa, ob = a.reset(), b.reset()
+    for t in range(60):
+        act = a.policy_random(oa).clone()
+        oa, ra, da = a.step(act, auto_reset=True)
+        ob, rb, db = b.step_random(auto_reset=True)
+        assert (b.action == act).all().item(), t
+        assert (oa.words == ob.words).all().item(), t
+        assert (da == db).all().item()
+    assert (a.state() == b.state()).all()
+    a.close(); b.close()
+
+
+def test_auto_reset_run_vs_oracle_full_size(T, O, S):
+    """tarok_run_random with auto-reset (wave-cooperative re-deal inside the step
+    kernel), graph-replayed and eager, at 65,536 games x 192 steps vs the oracle."""
+    n, seed, steps = 65536, 2, 192
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
+    for fused, chunk in [(False, 48), (True, 0), (True, 64)]:
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+        env.reset()
+        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True)
+        ep, ss = env.counters()
+        assert (ep == ref["episode"]).all(), (fused, chunk)
+        assert (ss == ref["score_sum"]).all(), (fused, chunk)
+        assert (env.state() == ref["lanes"]).all(), (fused, chunk)
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), (fused, chunk)
+        env.close()
+
+
+def test_sharded_envs_play_the_same_games(T, O, S):
+    """Two half-size envs with game_offset = what two ranks would hold."""
+    n, seed = 4096, 8
+    whole = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    w = whole.rollout_random(episode=0)
+    parts = []
+    for r in range(2):
+        e = T.TarokVecEnv(n // 2, seed=seed, mix=S.MIX_ALL, game_offset=r * n // 2)
+        parts.append(e.rollout_random(episode=0)["scores"].cpu().numpy())
+        e.close()
+    assert (np.concatenate(parts) == w["scores"].cpu().numpy()).all()
+    whole.close()
