@@ -8,16 +8,18 @@ uniform-random policy, synthetic deals).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one lock-step of every game = one card played in each of the 65,536
-games of a rank (Tarok.py:48-56): the random-policy kernel writes the action
-array, then tarok_step consumes it (state resident in HBM, observation word out),
-with auto-reset so every slot is live in every step.  value = games x steps x
-ranks / max-over-ranks time.  Weak scaling: each rank owns its own 65,536 games
+games of a rank (Tarok.py:48-56) = ONE launch of the step kernel: legal mask of
+the seat to move, a uniform random legal card (the Bot policy, Igralec.py:158-159),
+the card applied, trick resolution and scoring, finished games replaced at once
+(auto-reset: every slot is live in every step), next observation written.  State
+is resident in HBM between launches.  value = games x steps x ranks /
+max-over-ranks time.  Weak scaling: each rank owns its own 65,536 games
 (global game indices rank*65536...), no collective in the env path.
 
 Extra objects on the JSON line:
   roofline      the step kernel against HBM peak: algorithmic 54 B/step
-                x 65,536 games per launch / the kernel's launch duration measured
-                with HIP events bracketing single launches on the launch stream.
+                x 65,536 games per launch / launch duration, measured with HIP events
+                on the launch stream around the timed region.
   cpu_baseline  the CPU oracle (oracle/, a C port of the reference rules — test
                 infrastructure, used here only as the reported baseline) on the host
                 cores, bounded sample of the same workload.  rank 0, N=1 only.
@@ -72,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=480)
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--graph-chunk", type=int, default=48, help="steps per replayed hipGraph (0 = eager)")
+    ap.add_argument("--prefetch-every", type=int, default=4, help="deal finished slots' next games every k steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
     args = ap.parse_args()
@@ -91,7 +94,7 @@ def main():
     env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
 
     def run(steps, fused):
-        env.run_random(steps, fused=fused, graph_chunk=args.graph_chunk, auto_reset=True)
+        env.run_random(steps, fused=fused, graph_chunk=args.graph_chunk, auto_reset=True, prefetch_every=args.prefetch_every)
 
     def timed(steps, fused):
         sharding.barrier()
@@ -105,14 +108,30 @@ def main():
         sharding.max_over_ranks(t)
         return float(t.item())
 
-    # ---- headline: policy kernel + step kernel per step (the C-ABI step() path)
+    # ---- headline: one launch of tarok_step_random (k_step<true>: legal mask -> uniform
+    # random legal card -> apply -> trick/score -> auto-reset swap -> next observation) per
+    # lock-step, replayed as a hipGraph of `graph_chunk` steps; tarok_prefetch every
+    # `prefetch_every` steps deals the finished slots' next games.
     env.reset(episode=0)
-    run(args.warmup, False)
-    dt = timed(args.steps, False)
+    run(args.warmup, True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(dev)
+    sharding.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    run(args.steps, True)
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    sharding.barrier()
+    dt_local = time.perf_counter() - t0
+    tt = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+    sharding.max_over_ranks(tt)
+    dt = float(tt.item())
+    ev_ms = ev0.elapsed_time(ev1)
     total_steps = n * args.steps * world_size
     value = total_steps / dt
     ep, ss = env.counters()
-    episodes_finished = int(ep.sum())
 
     out = {
         "metric": "env steps/sec at 65,536 parallel 4-player games; 1/2/4/8 MI355X",
@@ -121,45 +140,39 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "configs[2]: %d parallel envs per GPU, mixed Klop/Berac/Navadna contracts "
                                "(1/3 Klop, 1/3 Berac incl. 1/2 open, 1/3 Navadna+Solo over 7 types), uniform random policy, "
-                               "auto-reset" % n,
-                   "games_per_gpu": n, "mode": "tarok_policy_random + tarok_step per step, hipGraph of %d steps" % args.graph_chunk,
-                   "parallelism": "games sharded %d-way, no collective in the env path" % world_size},
-        "episodes_finished_rank0": episodes_finished,
+                               "auto-reset (every slot live in every step)" % n,
+                   "games_per_gpu": n,
+                   "mode": "tarok_step_random: 1 kernel launch per lock-step (action, observation, done, scores "
+                           "materialised in HBM every step), hipGraph of %d steps, tarok_prefetch every %d steps"
+                           % (args.graph_chunk, args.prefetch_every),
+                   "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
+        "episodes_finished_rank0": int(ep.sum()),
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_step): HIP events around single launches
-        s = torch.cuda.current_stream(dev)
-        reps = 400
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        env.policy_random()
-        for _ in range(20):
-            env.step(env.action, auto_reset=True)
-            env.policy_random()
-        torch.cuda.synchronize(dev)
-        for e0, e1 in evs:
-            env.policy_random()
-            e0.record(s)
-            env.step(env.action, auto_reset=True)
-            e1.record(s)
-        torch.cuda.synchronize(dev)
-        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-        k_ms = sum(ts[reps // 10: -reps // 10]) / len(ts[reps // 10: -reps // 10])     # trimmed mean
+        # ---- roofline of the dominant kernel, k_step: HIP events on the launch stream around
+        # the timed region above; launch duration = region time / k_step launches (the
+        # region also holds 1 k_prefetch per `prefetch_every` steps and every launch gap, all
+        # charged to k_step -> a lower bound on its bandwidth).
+        k_us = ev_ms * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_STEP * n
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes_per_launch": algo_bytes, "kernel_us": k_ms * 1e3,
-                           "kernel_us_min": ts[0] * 1e3,
-                           "note": "54 B/step x %d games per launch / event-bracketed launch duration; "
-                                   "the 2 MB working set is cache resident at this N (see DESIGN.md N-sweep)" % n}
+        achieved = algo_bytes / (k_us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_step<true> (tarok_step_random)", "achieved": achieved,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us,
+                           "note": "54 B/step (SURVEY 8d) x %d games per launch / (HIP-event time of the timed region / "
+                                   "launches); at this N the per-GPU state (2 MB) is cache resident and the launch is "
+                                   "latency bound: see DESIGN.md for the N-sweep where HBM becomes the limiter" % n}
 
     if not args.no_extras:
-        # ---- side measurements (not `value`): fused policy+step kernel, whole-game rollout kernel
+        # ---- side measurements (not `value`)
+        # (a) the two-kernel C-ABI path: tarok_policy_random writes the action array, tarok_step consumes it
         env.reset(episode=0)
-        run(args.warmup, True)
-        dtf = timed(args.steps, True)
-        out["fused_step_random"] = {"value": total_steps / dtf, "unit": "env steps/s", "ms_per_step": dtf / args.steps * 1e3}
+        run(args.warmup, False)
+        dta = timed(args.steps, False)
+        out["api_two_kernel"] = {"value": total_steps / dta, "unit": "env steps/s", "ms_per_step": dta / args.steps * 1e3,
+                                 "note": "tarok_policy_random + tarok_step per lock-step (2 launches)"}
+        # (b) whole games per launch, state in registers
         sharding.barrier()
         torch.cuda.synchronize(dev)
         r = env.rollout_random(episode=0)
@@ -177,7 +190,8 @@ def main():
         sharding.sum_over_ranks(cnt)
         out["fused_rollout"] = {"value": float(cnt.item()) / float(tmax.item()), "unit": "env steps/s",
                                 "games_per_s": n * reps * world_size / float(tmax.item()),
-                                "note": "whole games in registers, one launch per 65,536 games; no per-step HBM state"}
+                                "note": "tarok_rollout_random: whole games in registers, one launch per %d games; "
+                                        "no per-step HBM state, so no HBM fraction is claimed for it" % n}
 
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(1 << 20, K.MIX_ALL)

@@ -130,6 +130,14 @@ int tarok_legal_actions(tarok_env *env, uint64_t *obs_out, int8_t *seat_out, voi
 int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8_t *done_out,
                uint64_t *obs_out, int flags, void *stream);
 
+/* Deal, ahead of time, the next game (episode+1, synthetic contract, Bot
+ * exchange) of every slot whose next-game buffer is empty.  With it a
+ * TAROK_AUTO_RESET step replaces a finished game by a 32-byte swap; call it at
+ * least every 4 steps (the shortest game, a lost Berac, is 4 cards).  Slots
+ * whose buffer is empty when they finish are dealt inside the step kernel
+ * instead (same result, slower).  tarok_reset calls it. */
+int tarok_prefetch(tarok_env *env, void *stream);
+
 /* Bot_igralec.igraj_karto (Igralec.py:158-159): uniform choice among the legal
  * cards, drawn from the spec RNG (draw 128 + cards played).  action_out[g] = 255
  * where nothing is to be played. */
@@ -142,10 +150,12 @@ int tarok_step_random(tarok_env *env, uint8_t *action_out, int16_t *reward_out, 
 /* n_steps lock-steps of the random policy, launched from C (optionally as a
  * replayed hipGraph of `graph_chunk` steps; 0 = eager launches).
  * fused = 0: tarok_policy_random + tarok_step per step;  1: tarok_step_random.
+ * prefetch_every = k > 0: tarok_prefetch after every k-th step (graph_chunk must
+ * be a multiple of k); only with TAROK_AUTO_RESET.
  * Buffers as in tarok_step (action [N] u8 scratch is required for fused = 0). */
-int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk, uint8_t *action,
-                     int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags,
-                     void *stream);
+int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk, int prefetch_every,
+                     uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
+                     int flags, void *stream);
 
 /* Whole games in one launch (state never leaves registers): deal + setup + Bot
  * exchange + random play to the end, for episode `episode` of every slot.

@@ -22,13 +22,15 @@ struct tarok_env {
     u64 offset, seed;
     int mix, flags;
     ulonglong2 *s01, *s23;   // packed state
+    ulonglong2 *n01, *n23;   // the slot's NEXT game, dealt ahead by k_prefetch (phase 0 = not ready)
+    uint8_t *nstale;         // 1 = next-game buffer empty (what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
     u32 *episode;            // episode number of the slot's current game
     int4 *score_sum;         // scores summed over finished games, by seat
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
     hipGraphExec_t gexec;
-    int g_fused, g_chunk, g_flags;
+    int g_fused, g_chunk, g_flags, g_prefetch;
     void *g_action, *g_reward, *g_done, *g_obs;
 };
 
@@ -60,13 +62,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     int64_t n, u64 seed, u64 offset, u32 episode, int mix, int flags,
     const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
     const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, u64 *__restrict__ gkey,
-    u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, ulonglong2 *__restrict__ n01,
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 key = game_key(seed, offset + (u64)i, episode);
     u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
     bool bad = false;
+    n01[i] = make_ulonglong2(0, 0);
+    nstale[i] = 1;
     if (deals) {
         const uint8_t *p = deals + i * 54;
         u64 h[4] = {0, 0, 0, 0};
@@ -103,6 +107,51 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     gkey[i] = key;
     ep[i] = episode;
     if (flags & TAROK_CLEAR_COUNTERS) score_sum[i] = make_int4(0, 0, 0, 0);
+}
+
+// Deal the NEXT game (episode+1, synthetic contract, Bot exchange) of every slot
+// whose next-game buffer is empty, so that a step that finishes a game only has
+// to swap 32 bytes in.  Only a few percent of the slots are empty at a time, so
+// each workgroup first compacts the empty slots of its 1024-slot tile into an
+// LDS list (4 flags per thread, one LDS atomic per thread that found any) and
+// then deals list entry j on thread j: the sorting-network deal runs on dense
+// lanes, and waves with nothing to do leave.
+#define TK_PF_SLOTS 1024
+__global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
+                                                      ulonglong2 *__restrict__ n01, ulonglong2 *__restrict__ n23,
+                                                      uint8_t *__restrict__ nstale, const u32 *__restrict__ ep) {
+    __shared__ unsigned short list[TK_PF_SLOTS];
+    __shared__ u32 count;
+    int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    u32 f = reinterpret_cast<const u32 *>(nstale + base)[threadIdx.x];   // 4 slots; array is padded
+    if (f) {
+        u32 c = ((f & 0xFF) != 0) + ((f & 0xFF00) != 0) + ((f & 0xFF0000) != 0) + ((f >> 24) != 0);
+        u32 pos = atomicAdd(&count, c);
+#pragma unroll
+        for (u32 k = 0; k < 4; k++)
+            if ((f >> (8 * k)) & 0xFF) list[pos++] = (unsigned short)(threadIdx.x * 4 + k);
+    }
+    __syncthreads();
+    u32 total = count;
+    for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) {
+        int64_t i = base + list[j];
+        if (i >= n) continue;
+        u64 key = game_key(seed, offset + (u64)i, (u64)ep[i] + 1);
+        u64 h0, h1, h2, h3, tal;
+        deal_thread(key, h0, h1, h2, h3, tal);
+        u32 c, d, k;
+        sample_setup(key, mix, c, d, k);
+        Game g;
+        setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+        if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
+        ulonglong2 a, b;
+        pack(g, a.x, a.y, b.x, b.y);
+        n23[i] = b;
+        n01[i] = a;
+        nstale[i] = 0;
+    }
 }
 
 __global__ __launch_bounds__(TK_BLOCK) void k_exchange(int64_t n, const int8_t *__restrict__ choice,
@@ -154,8 +203,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     int64_t n, u64 seed, u64 offset, int mix, int flags,
     const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
     int16_t *__restrict__ reward, uint8_t *__restrict__ done, u64 *__restrict__ obs,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, u64 *__restrict__ gkey,
-    u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, ulonglong2 *__restrict__ n01,
+    ulonglong2 *__restrict__ n23, uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u32 *__restrict__ ep,
+    int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
     int64_t ic = valid ? i : n - 1;
@@ -163,13 +213,23 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     load_game(g, s01, s23, ic);
     u64 key = 0;
     u32 a = 255;
+    if (RANDOM) key = gkey[ic]; else a = action[ic];
     bool play = valid && g.phase == TK_PHASE_PLAY;
+    bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
+    // A game can only end on the 4th card of a trick, and then only in trick 12
+    // or in a Berac.  For those few lanes the loads a finish needs (score sums,
+    // episode number, the prefetched next game) are issued NOW, next to the
+    // state load, instead of as a second memory round trip after the rules.
+    bool may_end = play && g.nt == 3 && (g.trick_no == 11 || g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC);
+    bool may_renew = autoreset && valid && (may_end || g.phase == TK_PHASE_DONE);
+    int4 acc = make_int4(0, 0, 0, 0);
+    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
+    u32 cur_ep = 0;
+    if (may_end) acc = score_sum[i];
+    if (may_renew) { na = n01[i]; nb = n23[i]; cur_ep = ep[i]; }
     if (RANDOM) {
-        key = gkey[ic];
         if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
         if (action_out && valid) action_out[i] = (uint8_t)a;
-    } else {
-        a = action[ic];
     }
     u64 scores = 0;
     int res = -2;
@@ -177,40 +237,56 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     bool fin = res == 1;
     if (fin) {
         if (reward) reinterpret_cast<u64 *>(reward)[i] = scores;
-        int4 acc = score_sum[i];
         acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
         acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
         score_sum[i] = acc;
     }
-    if (flags & TAROK_AUTO_RESET) {
-        u64 pend = __ballot(fin);
-        if (pend) {
+    bool renew = false;
+    if (autoreset) {
+        // every finished game is replaced by the slot's next one: normally a 32-byte
+        // swap from the prefetched buffer; if that is empty (tarok_prefetch not called
+        // for >= 4 steps) the wave deals it cooperatively right here.
+        renew = valid && g.phase == TK_PHASE_DONE;
+        if (__ballot(renew)) {
             u64 nkey = 0;
             u32 nep = 0;
-            if (fin) { nep = ep[i] + 1; nkey = game_key(seed, offset + (u64)i, nep); }
-            u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
-            u32 lane = __lane_id();
-            while (pend) {
-                int l = __builtin_ctzll(pend);
-                pend &= pend - 1;
-                u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)nkey, l);
-                u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(nkey >> 32), l);
-                u64 w0, w1, w2, w3, wt;
-                deal_wave(klo, khi, w0, w1, w2, w3, wt);
-                if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+            bool swapped = false;
+            if (renew) {
+                nep = cur_ep + 1;
+                nkey = game_key(seed, offset + (u64)i, nep);
+                if ((na.x >> 62) != 0) {
+                    unpack(g, na.x, na.y, nb.x, nb.y);
+                    reinterpret_cast<u64 *>(n01)[2 * i] = 0;
+                    nstale[i] = 1;
+                    swapped = true;
+                }
             }
-            if (fin) {
-                u32 c, d, k;
-                sample_setup(nkey, mix, c, d, k);
-                setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-                if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, nkey);
-                ep[i] = nep;
-                gkey[i] = nkey;
+            bool deal_here = renew && !swapped;
+            u64 pend = __ballot(deal_here);
+            if (pend) {
+                u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+                u32 lane = __lane_id();
+                while (pend) {
+                    int l = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)nkey, l);
+                    u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(nkey >> 32), l);
+                    u64 w0, w1, w2, w3, wt;
+                    deal_wave(klo, khi, w0, w1, w2, w3, wt);
+                    if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+                }
+                if (deal_here) {
+                    u32 c, d, k;
+                    sample_setup(nkey, mix, c, d, k);
+                    setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+                    if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, nkey);
+                }
             }
+            if (renew) { ep[i] = nep; gkey[i] = nkey; }
         }
     }
     if (valid) {
-        if (res != -2) store_game(g, s01, s23, i);
+        if (res != -2 || renew) store_game(g, s01, s23, i);
         obs[i] = obs_word(g, fin);
         if (done) done[i] = fin ? 1 : 0;
     }
@@ -318,6 +394,13 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->n01, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->n23, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMemset(e->n01, 0, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMemset(e->n23, 0, (size_t)n_games * sizeof(ulonglong2));
+    size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
+    if (r == hipSuccess) r = hipMalloc((void **)&e->nstale, stale_bytes);
+    if (r == hipSuccess) r = hipMemset(e->nstale, 0, stale_bytes);
     if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->episode, (size_t)n_games * sizeof(u32));
     if (r == hipSuccess) r = hipMalloc((void **)&e->score_sum, (size_t)n_games * sizeof(int4));
@@ -341,12 +424,18 @@ void tarok_destroy(tarok_env *e) {
     (void)hipSetDevice(e->device);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->gkey);
+    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->n01); (void)hipFree(e->n23); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
     (void)hipFree(e->episode); (void)hipFree(e->score_sum);
     delete e;
 }
 
 int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
+
+static inline void launch_prefetch(tarok_env *e, hipStream_t s) {
+    dim3 grid((unsigned)((e->n + TK_PF_SLOTS - 1) / TK_PF_SLOTS));
+    hipLaunchKernelGGL(k_prefetch, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, e->n01, e->n23,
+                       e->nstale, e->episode);
+}
 
 int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8_t *contract, const int8_t *declarer,
                 const int8_t *king_suit, const int8_t *talon_choice, const uint8_t *discards, int flags, void *stream) {
@@ -356,7 +445,16 @@ int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_reset, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
                        episode, e->mix, flags, deals, contract, declarer, king_suit, talon_choice, discards, e->s01,
-                       e->s23, e->gkey, e->episode, e->score_sum);
+                       e->s23, e->n01, e->nstale, e->gkey, e->episode, e->score_sum);
+    launch_prefetch(e, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_prefetch(tarok_env *e, void *stream) {
+    if (!e) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    launch_prefetch(e, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -383,12 +481,12 @@ static inline void launch_step(tarok_env *e, bool random, const uint8_t *action,
                                int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s) {
     if (random)
         hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->gkey, e->episode,
-                           e->score_sum);
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->n01, e->n23, e->nstale,
+                           e->gkey, e->episode, e->score_sum);
     else
         hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->gkey, e->episode,
-                           e->score_sum);
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->n01, e->n23, e->nstale,
+                           e->gkey, e->episode, e->score_sum);
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
@@ -428,27 +526,32 @@ static inline void launch_one(tarok_env *e, int fused, uint8_t *action, int16_t 
     }
 }
 
-int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, uint8_t *action, int16_t *reward_out,
-                     uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
-    if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 4096) return TAROK_EINVAL;
+int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, int prefetch_every, uint8_t *action,
+                     int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
+    if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 4096 || prefetch_every < 0) return TAROK_EINVAL;
+    if (graph_chunk > 0 && prefetch_every > 0 && graph_chunk % prefetch_every != 0) return TAROK_EINVAL;
+    if (!(flags & TAROK_AUTO_RESET)) prefetch_every = 0;
     if (!fused && !action) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     int64_t left = n_steps;
     if (graph_chunk > 0 && left >= graph_chunk) {
         bool hit = e->gexec && e->g_fused == fused && e->g_chunk == graph_chunk && e->g_flags == flags &&
+                   e->g_prefetch == prefetch_every &&
                    e->g_action == action && e->g_reward == reward_out && e->g_done == done_out && e->g_obs == obs_out;
         if (!hit) {
             if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-            for (int k = 0; k < graph_chunk; k++)
+            for (int k = 0; k < graph_chunk; k++) {
                 launch_one(e, fused, action, reward_out, done_out, obs_out, flags, e->cap_stream);
+                if (prefetch_every && (k + 1) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
+            }
             HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
             hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
-            e->g_fused = fused; e->g_chunk = graph_chunk; e->g_flags = flags;
+            e->g_fused = fused; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
             e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
         }
         while (left >= graph_chunk) {
@@ -456,7 +559,10 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, 
             left -= graph_chunk;
         }
     }
-    for (; left > 0; left--) launch_one(e, fused, action, reward_out, done_out, obs_out, flags, s);
+    for (int64_t k = 0; left > 0; left--, k++) {
+        launch_one(e, fused, action, reward_out, done_out, obs_out, flags, s);
+        if (prefetch_every && (k + 1) % prefetch_every == 0) launch_prefetch(e, s);
+    }
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

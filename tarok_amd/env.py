@@ -157,11 +157,16 @@ class TarokVecEnv:
                                                    self._stream()))
         return Obs(self.obs_words), self.reward, self.done
 
-    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True):
+    def prefetch(self):
+        """Deal every slot's next game ahead of time (call at least every 4 auto-reset steps)."""
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_prefetch(self._h, self._stream()))
+
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=4):
         """n_steps lock-steps of the random policy launched from C (optionally graph-replayed)."""
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_run_random(self._h, int(n_steps), 1 if fused else 0, int(graph_chunk),
-                                                  self._p(self.action), self._p(self.reward), self._p(self.done),
+                                                  int(prefetch_every), self._p(self.action), self._p(self.reward), self._p(self.done),
                                                   self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
                                                   self._stream()))
 

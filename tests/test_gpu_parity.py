@@ -251,16 +251,36 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     kernel), graph-replayed and eager, at 65,536 games x 192 steps vs the oracle."""
     n, seed, steps = 65536, 2, 192
     ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
-    for fused, chunk in [(False, 48), (True, 0), (True, 64)]:
+    # prefetch 4: every finished game is a 32-byte swap from the prefetched buffer;
+    # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
+    for fused, chunk, pf in [(False, 48, 4), (True, 0, 0), (True, 64, 16), (False, 0, 2)]:
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
-        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True)
+        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
         ep, ss = env.counters()
-        assert (ep == ref["episode"]).all(), (fused, chunk)
-        assert (ss == ref["score_sum"]).all(), (fused, chunk)
-        assert (env.state() == ref["lanes"]).all(), (fused, chunk)
-        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), (fused, chunk)
+        assert (ep == ref["episode"]).all(), (fused, chunk, pf)
+        assert (ss == ref["score_sum"]).all(), (fused, chunk, pf)
+        assert (env.state() == ref["lanes"]).all(), (fused, chunk, pf)
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), (fused, chunk, pf)
         env.close()
+
+
+def test_auto_reset_revives_games_finished_earlier(T, O, S):
+    """Games finished WITHOUT auto-reset are replaced by the first auto-reset step."""
+    n, seed = 2048, 31
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_FIXED + S.BERAC)
+    obs = env.reset()
+    for t in range(48):
+        obs, _, _ = env.step(env.policy_random(obs))
+    assert obs.done.all().item()
+    obs, _, done = env.step(env.policy_random(obs), auto_reset=True)    # no card played, new games swapped in
+    assert not done.any().item() and not obs.done.any().item()
+    st = env.state()
+    for i in range(0, n, 37):
+        assert (st[:, i] == O.Game.synth(seed, i, 1, S.MIX_FIXED + S.BERAC).lanes()).all()
+    ep, _ = env.counters()
+    assert (ep == 1).all()
+    env.close()
 
 
 def test_sharded_envs_play_the_same_games(T, O, S):
