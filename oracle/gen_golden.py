@@ -22,6 +22,8 @@ Files written:
     digests_v1.json  SHA-256 digests of the large synthetic configs
                      driven by oracle/tarok_spec.py's RNG, + known-answer micro vectors
     paralel_v1.npz   Tarok.paralel_start lock-step runs (Tarok.py:30-62) for the adapter
+    licitacija_v1.json  scripted bidding rounds: every licitiram call Igra.licitacija makes
+                     (seat, min_igra, obvezno, prednost, answer) and the outcome (Igra.py:75-114)
 """
 import argparse
 import hashlib
@@ -497,6 +499,66 @@ def gen_paralel(seed, n_games, mix):
                 setup=setup, per_game_scores=per_game, totals=np.array(totals, np.int64))
 
 
+# --------------------------------------------------------------------------
+# Igra.licitacija call/response scripts (Igra.py:75-114) -- host bidding fixture
+# --------------------------------------------------------------------------
+class ScriptCtl:
+    """Every licitiram call pops the next scripted desire of that seat; calls are logged."""
+
+    def __init__(self, scripts):
+        self.scripts = [list(x) for x in scripts]
+        self.calls = []
+        self.result = None
+
+    def on_nova_igra(self, p, roka, gid):
+        pass
+
+    def bid(self, p, gid, min_igra, obvezno, prednost):
+        T = REF["Tip_igre"].Tip_igre
+        seat = p.seat[gid]
+        want = self.scripts[seat].pop(0)
+        self.calls.append([seat, int(min_igra), (None if obvezno is None else int(obvezno)), bool(prednost), want])
+        return T(want)
+
+    def king(self, p, gid):
+        return 0
+
+    def on_konec_licitiranja(self, p, decl, tip, gid, barva):
+        self.result = [decl.seat[gid], int(tip)]
+
+
+def gen_bidding(n_cases, seed):
+    rnd = random.Random(seed)
+    T = REF["Tip_igre"].Tip_igre
+    vals = [int(t) for t in T]
+    cases = []
+    IgraMod = REF["Igra"]
+    IgraMod.shuffle = lambda lst: None
+    for n in range(n_cases):
+        style = n % 3
+        scripts = []
+        for seat in range(4):
+            if style == 0:      # the Bot's distribution (Igralec.py:151)
+                sc = [rnd.choice([-10, -10, -10, 10, 20, 30]) for _ in range(40)]
+            elif style == 1:    # anything goes
+                sc = [rnd.choice(vals) for _ in range(40)]
+            else:               # stubborn: constant desire
+                sc = [rnd.choice(vals)] * 40
+            scripts.append(sc)
+        ctl = ScriptCtl(scripts)
+        players = [TracePlayer(i, ctl) for i in range(4)]
+        ig = IgraMod.Igra(players, multi_games=True, id=0)
+        gen = ig.start()
+        next(gen)                        # 'Pripravljen_licitirat'
+        try:
+            next(gen)                    # runs licitacija + konec_licitiranja, returns the engine generator
+        except Exception as e:           # noqa: BLE001  (e.g. scripts exhausted: skip the case)
+            continue
+        cases.append(dict(scripts=[sc[:12] for sc in scripts], calls=ctl.calls, result=ctl.result))
+        assert all(len(c) for c in ctl.calls) and max(len(ctl.calls), 0) < 40
+    return cases
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -504,9 +566,17 @@ def main():
     ap.add_argument("--per-contract", type=int, default=288)
     ap.add_argument("--procs", type=int, default=max(1, (os.cpu_count() or 2) - 1))
     ap.add_argument("--skip-large", action="store_true")
+    ap.add_argument("--only-bidding", action="store_true")
     args = ap.parse_args()
     load_reference(args.reference)
     os.makedirs(args.out, exist_ok=True)
+
+    bid = gen_bidding(1500, seed=77)
+    with open(os.path.join(args.out, "licitacija_v1.json"), "w") as f:
+        json.dump(bid, f, separators=(",", ":"))
+    print("bidding cases:", len(bid))
+    if args.only_bidding:
+        return
 
     tr = gen_traces(args.per_contract, seed=20261004)
     np.savez_compressed(os.path.join(args.out, "traces_v1.npz"), **tr)

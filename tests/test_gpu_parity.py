@@ -295,3 +295,105 @@ def test_sharded_envs_play_the_same_games(T, O, S):
         e.close()
     assert (np.concatenate(parts) == w["scores"].cpu().numpy()).all()
     whole.close()
+
+
+class _SpecPlayer:
+    """Duck-typed reference-shaped player (NOT an Igralec subclass): plays the spec's
+    deterministic policy keyed by game id — the same one gen_golden.py's ParalelCtl drove
+    the reference's Tarok.paralel_start with."""
+
+    def __init__(self, ime, S, seed, mix, shared):
+        self.ime, self.S, self.seed, self.mix, self.shared = str(ime), S, seed, mix, shared
+        self.roka, self.kupcek, self.seat = {}, {}, {}
+
+    def _key(self, g):
+        return self.S.game_key(self.seed, g, 0)
+
+    def _setup(self, g):
+        S = self.S
+        c, d, k = S.sample_setup(self._key(g), self.mix)
+        if not (d == 0 or c >= S.DVE) or c == S.KLOP:
+            d = 0
+        return c, d, k
+
+    def nova_igra(self, roka, igralci, g):
+        self.roka[g], self.kupcek[g] = roka, []
+        self.seat[g] = [i for i, p in enumerate(igralci) if p is self][0]
+        self.shared.setdefault("steps", {})[g] = 0
+
+    def licitiram(self, min_igra, g, obvezno=None, prednost=False):
+        from tarok_amd import licitacija as L
+        c, d, k = self._setup(g)
+        want = c * 10 if (self.seat[g] == d and c != self.S.KLOP) else L.NAPREJ
+        return L.base_filter(want, min_igra, obvezno, prednost)
+
+    def izberi_barvo_kralja(self, g):
+        return self._setup(g)[2]
+
+    def konec_licitiranja(self, *a):
+        pass
+
+    def menjaj_iz_talona(self, kupcki, st_kart, g):
+        from tarok_amd import igralec as I, karte as K
+        self.roka[g].dodaj_karte(kupcki[0])
+        hand = K.ids_to_mask(k.v_id() for k in self.roka[g])
+        for cid in self.S.bot_discards(self._key(g), hand, st_kart):
+            k = I.Karta.iz_id(cid)
+            self.kupcek[g].append(k)
+            self.roka[g].igraj_karto(k)
+        return 0
+
+    def pripravi_igraj_karto(self, stih, mozne, zgodovina, g):
+        pass
+
+    def igraj_karto(self, stih, mozne, zgodovina, g):
+        from tarok_amd import karte as K
+        t = self.shared["steps"][g]
+        self.shared["steps"][g] = t + 1
+        cid = self.S.policy_action(self._key(g), t, K.ids_to_mask(k.v_id() for k in mozne))
+        karta = [k for k in mozne if k.v_id() == cid][0]
+        self.roka[g].igraj_karto(karta)
+        return karta
+
+    def rezultat_stiha(self, stih, sem_pobral, g):
+        if sem_pobral:
+            self.shared.setdefault("tricks", {}).setdefault(g, []).append(len(stih))
+
+    def rezultat_igre(self, pts, zgodovina, g):
+        self.shared.setdefault("scores", {}).setdefault(g, {})[self.ime] = int(pts)
+
+
+def test_paralel_start_adapter_matches_reference_run(T, S, golden_dir):
+    """tarok_amd.igralec.Tarok.paralel_start (callbacks served from the GPU env) against the
+    reference's own Tarok.paralel_start on the same deals, bids and card choices."""
+    from tarok_amd import igralec as I
+    ref = dict(np.load(os.path.join(golden_dir, "paralel_v1.npz")))
+    n, seed, mix = len(ref["deals"]), int(ref["seed"]), int(ref["mix"])
+    shared = {}
+    players = [_SpecPlayer(i, S, seed, mix, shared) for i in range(4)]
+    t = I.Tarok(players, n, seed=seed)
+    rez = t.paralel_start()
+    assert [rez[p] for p in players] == [int(x) for x in ref["totals"]]
+    for g in range(n):
+        assert [shared["scores"][g][str(i)] for i in range(4)] == [int(x) for x in ref["per_game_scores"][g]], g
+        d, c, _ = t.zadnje_igre[g]
+        assert (c // 10, d) == (int(ref["setup"][g][0]), int(ref["setup"][g][1])), g
+        if c == 0:      # Klop: tricks 1-6 carry the talon card (Klop.py:67-71)
+            assert shared["tricks"][g] == [5] * 6 + [4] * 6
+
+
+def test_paralel_start_with_bot_players(T):
+    """Reference-shaped random players through the adapter: runs, scores are well-formed."""
+    import random
+    from tarok_amd import igralec as I
+    bots = [I.Bot_igralec(i, rng=random.Random(100 + i)) for i in range(4)]
+    t = I.Tarok(bots, 64, seed=3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rez = t.paralel_start()
+    assert len(t.zadnje_igre) == 64
+    for d, c, sc in t.zadnje_igre:
+        assert c in (0, 10, 20, 30)             # the Bot only bids Tri/Dve/Ena (Igralec.py:151)
+        assert all(len(b.roka[g]) == 0 for g, b in [(0, bots[0])])
+    assert sum(rez.values()) == sum(sum(sc) for _, _, sc in t.zadnje_igre)
