@@ -82,10 +82,14 @@ def main():
     import torch
     from tarok_amd import TarokVecEnv, karte as K, sharding
 
+    import tarok_amd
+    tarok_amd.build()                       # no-op when libtarokenv.so is current (hipcc, gfx950)
     rank, local_rank, world_size = sharding.world()
+    if os.environ.get("TAROK_BENCH_ONE_GPU"):   # rehearsal: all ranks share GPU 0, gloo for the barrier
+        local_rank = 0
     if world_size > 1:
         torch.cuda.set_device(local_rank)
-        sharding.init_process_group("nccl")
+        sharding.init_process_group("gloo" if os.environ.get("TAROK_BENCH_ONE_GPU") else "nccl")
     if args.gpus != world_size and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world_size), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -104,9 +108,7 @@ def main():
         torch.cuda.synchronize(dev)
         sharding.barrier()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        sharding.max_over_ranks(t)
-        return float(t.item())
+        return sharding.max_over_ranks([dt])[0]
 
     # ---- headline: one launch of tarok_step_random (k_step<true>: legal mask -> uniform
     # random legal card -> apply -> trick/score -> auto-reset swap -> next observation) per
@@ -125,9 +127,7 @@ def main():
     torch.cuda.synchronize(dev)
     sharding.barrier()
     dt_local = time.perf_counter() - t0
-    tt = torch.tensor([dt_local], dtype=torch.float64, device=dev)
-    sharding.max_over_ranks(tt)
-    dt = float(tt.item())
+    dt = sharding.max_over_ranks([dt_local])[0]
     ev_ms = ev0.elapsed_time(ev1)
     total_steps = n * args.steps * world_size
     value = total_steps / dt
@@ -183,13 +183,10 @@ def main():
             r = env.rollout_random(episode=1 + e)
         torch.cuda.synchronize(dev)
         dtr = time.perf_counter() - t0
-        st = torch.tensor([float(r["nsteps"].sum().item()) * reps, dtr], dtype=torch.float64, device=dev)
-        tmax = st[1:2].clone()
-        sharding.max_over_ranks(tmax)
-        cnt = st[0:1].clone()
-        sharding.sum_over_ranks(cnt)
-        out["fused_rollout"] = {"value": float(cnt.item()) / float(tmax.item()), "unit": "env steps/s",
-                                "games_per_s": n * reps * world_size / float(tmax.item()),
+        tmax = sharding.max_over_ranks([dtr])[0]
+        cnt = sharding.sum_over_ranks([float(r["nsteps"].sum().item()) * reps])[0]
+        out["fused_rollout"] = {"value": cnt / tmax, "unit": "env steps/s",
+                                "games_per_s": n * reps * world_size / tmax,
                                 "note": "tarok_rollout_random: whole games in registers, one launch per %d games; "
                                         "no per-step HBM state, so no HBM fraction is claimed for it" % n}
 

@@ -173,23 +173,27 @@ __device__ __forceinline__ u64 score_navadna(const Game &g) {
 // -1 = not a legal card: nothing changes except the error bit.
 __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores) {
     u64 legal = legal_now(g);
-    if (a >= 54 || !((legal >> a) & 1)) { g.error = 1; return -1; }
+    bool ok = a < 54 && ((legal >> (a & 63)) & 1);
+    g.error = ok ? g.error : 1u;     // (select, not a conditional store: keeps the struct in registers)
+    if (!ok) return -1;
     g.C |= 1ULL << a;
     g.trick |= a << (6 * g.nt);
     g.nt++;
     if (g.nt < 4) return 0;
     // pobere_stih / primerjaj_karti (Klop.py:81-94)
-    u32 c[4] = {g.trick & 63, (g.trick >> 6) & 63, (g.trick >> 12) & 63, (g.trick >> 18) & 63};
-    u32 w = 0, cw = c[0];
-#pragma unroll
-    for (u32 i = 1; i < 4; i++) {
-        u32 sw = min(cw >> 3, 4u), si = min(c[i] >> 3, 4u);
-        bool beats = (sw == si) ? (cw < c[i]) : (si == 4);
-        w = beats ? i : w;
-        cw = beats ? c[i] : cw;
+    u32 c0 = g.trick & 63, c1 = (g.trick >> 6) & 63, c2 = (g.trick >> 12) & 63, c3 = (g.trick >> 18) & 63;
+    u32 w = 0, cw = c0;
+#define TK_CHALLENGE(ci, i)                                          \
+    {                                                                \
+        u32 sw = min(cw >> 3, 4u), si = min((ci) >> 3, 4u);          \
+        bool beats = (sw == si) ? (cw < (ci)) : (si == 4);           \
+        w = beats ? (i) : w;                                         \
+        cw = beats ? (ci) : cw;                                      \
     }
+    TK_CHALLENGE(c1, 1u) TK_CHALLENGE(c2, 2u) TK_CHALLENGE(c3, 3u)
+#undef TK_CHALLENGE
     u32 ws = (g.leader + w) & 3;
-    u64 tm = (1ULL << c[0]) | (1ULL << c[1]) | (1ULL << c[2]) | (1ULL << c[3]);
+    u64 tm = (1ULL << c0) | (1ULL << c1) | (1ULL << c2) | (1ULL << c3);
     if (g.contract == TK_KLOP && g.tl > 0) {                              // talon gift, Klop.py:67-71
         g.tl--;
         tm |= 1ULL << ((g.talon >> (6 * g.tl)) & 63);
@@ -243,27 +247,31 @@ __device__ __forceinline__ void setup_game(Game &g, u64 h0, u64 h1, u64 h2, u64 
 // false = rejected (bad group, card not in hand, duplicate): error bit set.
 __device__ __forceinline__ bool apply_exchange(Game &g, u32 choice, u32 d0, u32 d1, u32 d2) {
     u32 gs = group_size(g.contract);
-    if (choice >= 6 / gs) { g.error = 1; return false; }
+    u32 ngroups = gs == 3 ? 2u : (gs == 2 ? 3u : 6u);
     u64 grp = ids_mask(g.talon, (int)(choice * gs), (int)gs);
     u64 h = hand_of(g, g.declarer) | grp;
-    u32 d[3] = {d0, d1, d2};
+    u32 dpk = (d0 & 255) | ((d1 & 255) << 8) | ((d2 & 255) << 16);
     u64 dm = 0;
-    bool ok = true;
+    bool ok = choice < ngroups;
 #pragma unroll
-    for (u32 i = 0; i < 3; i++)
-        if (i < gs) {
-            bool good = d[i] < 54 && ((h >> (d[i] & 63)) & 1) && !((dm >> (d[i] & 63)) & 1);
-            ok = ok && good;
-            dm |= good ? (1ULL << d[i]) : 0;
-        }
-    if (!ok) { g.error = 1; return false; }
+    for (u32 i = 0; i < 3; i++) {
+        u32 di = (dpk >> (8 * i)) & 255;
+        bool good = di < 54 && ((h >> (di & 63)) & 1) && !((dm >> (di & 63)) & 1);
+        ok = ok && (good || i >= gs);
+        dm |= (good && i < gs) ? (1ULL << (di & 63)) : 0;
+    }
+    // all-select update (no conditional stores to different fields: they would push the struct to scratch)
     u32 s = g.declarer;
-    g.A = (g.A & ~grp) | ((s & 1) ? grp : 0);
-    g.B = (g.B & ~grp) | ((s & 2) ? grp : 0);
-    g.C = (g.C & ~grp) | dm;
-    g.tl = choice;
-    g.phase = TK_PHASE_PLAY;
-    return true;
+    u64 nA = (g.A & ~grp) | ((s & 1) ? grp : 0);
+    u64 nB = (g.B & ~grp) | ((s & 2) ? grp : 0);
+    u64 nC = (g.C & ~grp) | dm;
+    g.A = ok ? nA : g.A;
+    g.B = ok ? nB : g.B;
+    g.C = ok ? nC : g.C;
+    g.tl = ok ? choice : g.tl;
+    g.phase = ok ? (u32)TK_PHASE_PLAY : g.phase;
+    g.error = ok ? g.error : 1u;
+    return ok;
 }
 
 // ---------------------------------------------------------------------------
@@ -330,15 +338,15 @@ __device__ __forceinline__ void bot_exchange(Game &g, u64 key) {
     u64 h = hand_of(g, g.declarer) | ids_mask(g.talon, 0, (int)gs);
     u64 cand = h & TK_DISCARDABLE;
     if ((u32)popc64(cand) < gs) cand = h;
-    u32 d[3] = {255, 255, 255};
+    u32 dpk = 0xFFFFFF;
 #pragma unroll
     for (u32 j = 0; j < 3; j++)
         if (j < gs) {
             u32 c = kth_bit(cand, pick(rng32(key, 68 + j), (u32)popc64(cand)));
-            d[j] = c;
+            dpk = (dpk & ~(255u << (8 * j))) | (c << (8 * j));
             cand &= ~(1ULL << c);
         }
-    apply_exchange(g, 0, d[0], d[1], d[2]);
+    apply_exchange(g, 0, dpk & 255, (dpk >> 8) & 255, (dpk >> 16) & 255);
 }
 
 // The deal: sort the 54 cards by (random key | card id); position p of the

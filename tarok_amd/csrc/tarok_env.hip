@@ -16,17 +16,25 @@
 
 #define TK_BLOCK 256
 
+// Per-slot side record, one 64-byte line: everything a FINISHING game touches
+// (its score sums, episode number and the prefetched next game) sits together,
+// so the sparse finish path costs one line instead of four.
+struct __attribute__((aligned(64))) Aux {
+    ulonglong2 n01, n23;   // the slot's NEXT game, dealt ahead by k_prefetch (phase bits 0 = not ready)
+    int4 score_sum;        // scores summed over finished games, by seat (Tarok.rezultati)
+    u32 episode;           // episode number of the slot's current game
+    u32 pad[3];
+};
+
 struct tarok_env {
     int device;
     int64_t n;
     u64 offset, seed;
     int mix, flags;
     ulonglong2 *s01, *s23;   // packed state
-    ulonglong2 *n01, *n23;   // the slot's NEXT game, dealt ahead by k_prefetch (phase 0 = not ready)
+    Aux *aux;                // finish-path record per slot
     uint8_t *nstale;         // 1 = next-game buffer empty (what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
-    u32 *episode;            // episode number of the slot's current game
-    int4 *score_sum;         // scores summed over finished games, by seat
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
     hipGraphExec_t gexec;
@@ -62,14 +70,14 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     int64_t n, u64 seed, u64 offset, u32 episode, int mix, int flags,
     const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
     const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, ulonglong2 *__restrict__ n01,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u32 *__restrict__ ep, int4 *__restrict__ score_sum) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 key = game_key(seed, offset + (u64)i, episode);
     u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
     bool bad = false;
-    n01[i] = make_ulonglong2(0, 0);
+    aux[i].n01 = make_ulonglong2(0, 0);
     nstale[i] = 1;
     if (deals) {
         const uint8_t *p = deals + i * 54;
@@ -105,8 +113,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     if (bad) g.error = 1;
     store_game(g, s01, s23, i);
     gkey[i] = key;
-    ep[i] = episode;
-    if (flags & TAROK_CLEAR_COUNTERS) score_sum[i] = make_int4(0, 0, 0, 0);
+    aux[i].episode = episode;
+    if (flags & TAROK_CLEAR_COUNTERS) aux[i].score_sum = make_int4(0, 0, 0, 0);
 }
 
 // Deal the NEXT game (episode+1, synthetic contract, Bot exchange) of every slot
@@ -118,8 +126,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
 // lanes, and waves with nothing to do leave.
 #define TK_PF_SLOTS 1024
 __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
-                                                      ulonglong2 *__restrict__ n01, ulonglong2 *__restrict__ n23,
-                                                      uint8_t *__restrict__ nstale, const u32 *__restrict__ ep) {
+                                                      Aux *__restrict__ aux, uint8_t *__restrict__ nstale) {
     __shared__ unsigned short list[TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
     for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) {
         int64_t i = base + list[j];
         if (i >= n) continue;
-        u64 key = game_key(seed, offset + (u64)i, (u64)ep[i] + 1);
+        u64 key = game_key(seed, offset + (u64)i, (u64)aux[i].episode + 1);
         u64 h0, h1, h2, h3, tal;
         deal_thread(key, h0, h1, h2, h3, tal);
         u32 c, d, k;
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
         ulonglong2 a, b;
         pack(g, a.x, a.y, b.x, b.y);
-        n23[i] = b;
-        n01[i] = a;
+        aux[i].n23 = b;
+        aux[i].n01 = a;
         nstale[i] = 0;
     }
 }
@@ -203,9 +210,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     int64_t n, u64 seed, u64 offset, int mix, int flags,
     const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
     int16_t *__restrict__ reward, uint8_t *__restrict__ done, u64 *__restrict__ obs,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, ulonglong2 *__restrict__ n01,
-    ulonglong2 *__restrict__ n23, uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u32 *__restrict__ ep,
-    int4 *__restrict__ score_sum) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
     int64_t ic = valid ? i : n - 1;
@@ -225,8 +231,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     int4 acc = make_int4(0, 0, 0, 0);
     ulonglong2 na = make_ulonglong2(0, 0), nb = na;
     u32 cur_ep = 0;
-    if (may_end) acc = score_sum[i];
-    if (may_renew) { na = n01[i]; nb = n23[i]; cur_ep = ep[i]; }
+    if (may_end) acc = aux[i].score_sum;
+    if (may_renew) { na = aux[i].n01; nb = aux[i].n23; cur_ep = aux[i].episode; }
     if (RANDOM) {
         if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
         if (action_out && valid) action_out[i] = (uint8_t)a;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
         if (reward) reinterpret_cast<u64 *>(reward)[i] = scores;
         acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
         acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
-        score_sum[i] = acc;
+        aux[i].score_sum = acc;
     }
     bool renew = false;
     if (autoreset) {
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
                 nkey = game_key(seed, offset + (u64)i, nep);
                 if ((na.x >> 62) != 0) {
                     unpack(g, na.x, na.y, nb.x, nb.y);
-                    reinterpret_cast<u64 *>(n01)[2 * i] = 0;
+                    aux[i].n01.x = 0;
                     nstale[i] = 1;
                     swapped = true;
                 }
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
                     if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, nkey);
                 }
             }
-            if (renew) { ep[i] = nep; gkey[i] = nkey; }
+            if (renew) { aux[i].episode = nep; gkey[i] = nkey; }
         }
     }
     if (valid) {
@@ -327,6 +333,14 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
     }
     if (scores_out) reinterpret_cast<u64 *>(scores_out)[i] = scores;
     if (nsteps_out) nsteps_out[i] = (int16_t)played;
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Aux *__restrict__ aux, u32 *__restrict__ ep,
+                                                      int4 *__restrict__ score_sum) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (ep) ep[i] = aux[i].episode;
+    if (score_sum) score_sum[i] = aux[i].score_sum;
 }
 
 // canonical lanes for parity checks: H0-3, P0-3, TAL, META (tarok_env.h)
@@ -392,23 +406,17 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     tarok_env *e = new tarok_env();
     memset(e, 0, sizeof *e);
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
+    size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->n01, (size_t)n_games * sizeof(ulonglong2));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->n23, (size_t)n_games * sizeof(ulonglong2));
-    if (r == hipSuccess) r = hipMemset(e->n01, 0, (size_t)n_games * sizeof(ulonglong2));
-    if (r == hipSuccess) r = hipMemset(e->n23, 0, (size_t)n_games * sizeof(ulonglong2));
-    size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
+    if (r == hipSuccess) r = hipMalloc((void **)&e->aux, (size_t)n_games * sizeof(Aux));
     if (r == hipSuccess) r = hipMalloc((void **)&e->nstale, stale_bytes);
-    if (r == hipSuccess) r = hipMemset(e->nstale, 0, stale_bytes);
     if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->episode, (size_t)n_games * sizeof(u32));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->score_sum, (size_t)n_games * sizeof(int4));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
+    if (r == hipSuccess) r = hipMemset(e->aux, 0, (size_t)n_games * sizeof(Aux));
+    if (r == hipSuccess) r = hipMemset(e->nstale, 0, stale_bytes);
     if (r == hipSuccess) r = hipMemset(e->gkey, 0, (size_t)n_games * sizeof(u64));
-    if (r == hipSuccess) r = hipMemset(e->episode, 0, (size_t)n_games * sizeof(u32));
-    if (r == hipSuccess) r = hipMemset(e->score_sum, 0, (size_t)n_games * sizeof(int4));
     if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking);
     if (r != hipSuccess) {
         g_last_hip = (int)r;
@@ -424,8 +432,7 @@ void tarok_destroy(tarok_env *e) {
     (void)hipSetDevice(e->device);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->n01); (void)hipFree(e->n23); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
-    (void)hipFree(e->episode); (void)hipFree(e->score_sum);
+    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
     delete e;
 }
 
@@ -433,8 +440,7 @@ int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
 
 static inline void launch_prefetch(tarok_env *e, hipStream_t s) {
     dim3 grid((unsigned)((e->n + TK_PF_SLOTS - 1) / TK_PF_SLOTS));
-    hipLaunchKernelGGL(k_prefetch, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, e->n01, e->n23,
-                       e->nstale, e->episode);
+    hipLaunchKernelGGL(k_prefetch, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, e->aux, e->nstale);
 }
 
 int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8_t *contract, const int8_t *declarer,
@@ -445,7 +451,7 @@ int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_reset, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
                        episode, e->mix, flags, deals, contract, declarer, king_suit, talon_choice, discards, e->s01,
-                       e->s23, e->n01, e->nstale, e->gkey, e->episode, e->score_sum);
+                       e->s23, e->aux, e->nstale, e->gkey);
     launch_prefetch(e, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
@@ -481,12 +487,12 @@ static inline void launch_step(tarok_env *e, bool random, const uint8_t *action,
                                int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s) {
     if (random)
         hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->n01, e->n23, e->nstale,
-                           e->gkey, e->episode, e->score_sum);
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
+                           e->gkey);
     else
         hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->n01, e->n23, e->nstale,
-                           e->gkey, e->episode, e->score_sum);
+                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
+                           e->gkey);
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
@@ -589,10 +595,9 @@ int tarok_get_state(tarok_env *e, uint64_t *lanes_out, void *stream) {
 int tarok_get_counters(tarok_env *e, uint32_t *episode_out, int32_t *score_sum_out, void *stream) {
     if (!e) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    if (episode_out)
-        HIPCHK(hipMemcpyAsync(episode_out, e->episode, (size_t)e->n * sizeof(u32), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    if (score_sum_out)
-        HIPCHK(hipMemcpyAsync(score_sum_out, e->score_sum, (size_t)e->n * sizeof(int4), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    hipLaunchKernelGGL(k_counters, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->aux, episode_out,
+                       (int4 *)score_sum_out);
+    HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
 

@@ -38,19 +38,28 @@ def init_process_group(backend=None):
     dist.init_process_group(backend=backend, rank=world()[0], world_size=world()[2])
 
 
-def sum_over_ranks(t):
-    """In-place SUM all-reduce of a small tensor (score totals, step counts)."""
+def _reduce(values, op):
+    """All-reduce a short list of floats/ints; returns a list.  Uses a device tensor under
+    nccl (RCCL) and a host tensor under gloo, so the same code runs in CPU rehearsals."""
+    import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return list(values)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=op)
+    return t.cpu().tolist()
 
 
-def max_over_ranks(t):
+def sum_over_ranks(values):
+    """SUM over ranks of a short list (score totals, step counts)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t
+    return _reduce(values, dist.ReduceOp.SUM)
+
+
+def max_over_ranks(values):
+    import torch.distributed as dist
+    return _reduce(values, dist.ReduceOp.MAX)
 
 
 def barrier():

@@ -20,6 +20,7 @@ def T():
     assert torch.cuda.is_available(), "these tests need the MI355X"
     import tarok_amd
     from tarok_amd import _native
+    tarok_amd.build()
     assert os.path.exists(_native.LIB_PATH), "libtarokenv.so missing: the HIP path is the product, no fallback"
     return tarok_amd
 

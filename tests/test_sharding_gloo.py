@@ -32,14 +32,12 @@ def _worker(rank, world_size, port, n_total, seed, mix, q):
     assert sharding.world() == (rank, rank, world_size)
     off, cnt = sharding.strong_shard(n_total, rank, world_size)
     r = O.rollout(seed, off, cnt, 0, mix, trace=False)
-    totals = torch.tensor(list(r["scores"].astype(np.int64).sum(0)) + [r["total_steps"]], dtype=torch.int64)
-    sharding.sum_over_ranks(totals)
-    t = torch.tensor([float(rank + 1)])
-    sharding.max_over_ranks(t)
+    totals = sharding.sum_over_ranks(list(r["scores"].astype(np.int64).sum(0)) + [r["total_steps"]])
+    t = sharding.max_over_ranks([float(rank + 1)])
     sharding.barrier()
     woff, wcnt = sharding.weak_shard(100, rank)
     if rank == 0:
-        q.put((totals.tolist(), t.item(), (woff, wcnt)))
+        q.put(([int(x) for x in totals], t[0], (woff, wcnt)))
     dist.destroy_process_group()
 
 
