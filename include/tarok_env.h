@@ -166,6 +166,10 @@ int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk
 int tarok_rollout_random(tarok_env *env, uint32_t episode, int16_t *scores_out, int16_t *nsteps_out,
                          int8_t *seats_out, uint64_t *masks_out, uint8_t *actions_out, void *stream);
 
+/* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
+ * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */
+int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);
+
 /* Canonical state for parity checks / checkpoints: lanes_out [10,N] u64. */
 int tarok_get_state(tarok_env *env, uint64_t *lanes_out, void *stream);
 /* Per-slot bookkeeping: episode_out [N] u32 (current episode number),

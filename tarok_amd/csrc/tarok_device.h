@@ -97,12 +97,14 @@ __device__ __forceinline__ u64 talon_unowned(const Game &g) {
 }
 
 // Roka.prestej (Roka.py:56-98), order independent:
-// sum(val) - 2*floor(n/3) - [n%3 != 0]
+// sum(val) - 2*floor(n/3) - [n%3 != 0].  The values 1..5 are summed as nested
+// popcounts (v_bcnt accumulates for free); n <= 54 so n/3 = (n*43)>>7.
 __device__ __forceinline__ int prestej(u64 m) {
-    int n = popc64(m);
-    int v = n + 4 * popc64(m & TK_V5) + 3 * popc64(m & TK_V4) + 2 * popc64(m & TK_V3) + popc64(m & TK_V2);
-    int q = n / 3;
-    return v - 2 * q - (n != 3 * q);
+    u32 n = (u32)popc64(m);
+    u32 v = n + (u32)popc64(m & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + (u32)popc64(m & (TK_V3 | TK_V4 | TK_V5)) +
+            (u32)popc64(m & (TK_V4 | TK_V5)) + (u32)popc64(m & TK_V5);
+    u32 q = (n * 43u) >> 7;
+    return (int)(v - 2 * q - (n != 3 * q ? 1u : 0u));
 }
 
 // mozne_karte: Navadna_igra.py:158-168; Klop.py:96-133 adds "pagat only when
@@ -137,33 +139,37 @@ __device__ __forceinline__ u64 pack_scores(int s0, int s1, int s2, int s3) {
            ((u64)(uint16_t)(int16_t)s2 << 32) | ((u64)(uint16_t)(int16_t)s3 << 48);
 }
 
-// Klop.start scoring (Klop.py:36-45): -points each; if anybody took more than
-// 35 everybody scores 0 (the -70 branch at Klop.py:39-40 is unreachable).
-__device__ __forceinline__ u64 score_klop(const Game &g) {
-    int c0 = prestej(seat_cards(g, 0) & g.C), c1 = prestej(seat_cards(g, 1) & g.C);
-    int c2 = prestej(seat_cards(g, 2) & g.C), c3 = prestej(seat_cards(g, 3) & g.C);
-    bool over = c0 > 35 || c1 > 35 || c2 > 35 || c3 > 35;
-    return over ? 0ULL : pack_scores(-c0, -c1, -c2, -c3);
-}
-
-// Navadna_igra.start scoring (Navadna_igra.py:80-113)
-__device__ __forceinline__ u64 score_navadna(const Game &g) {
-    u64 rest = talon_unowned(g);
-    u64 won = g.C & ~rest;
-    u64 t = 0;
-#pragma unroll
-    for (u32 s = 0; s < 4; s++)
-        if ((g.team >> s) & 1) t |= seat_cards(g, s) & won;
+// End-of-game scoring, Klop and Navadna/Solo in one straight-line pass (lanes of a
+// wave finish different contracts in the same step; two separate routines would
+// both be paid by every such wave).
+//   Klop (Klop.py:36-45): -points each; if anybody took more than 35 everybody
+//     scores 0 (the -70 branch at Klop.py:39-40 is unreachable).
+//   Navadna/Solo (Navadna_igra.py:80-113): team pile (+ the talon rest only in the
+//     narrow case of :87), v -> sign(contract) + round-to-5 of (v-35).
+// Un-owned talon cards sit in an OPPONENT's pile bits from the start (setup_game),
+// so the team pile needs no masking; the rest mask is rebuilt only for :87.
+__device__ __forceinline__ u64 score_game(const Game &g) {
+    bool klop = g.contract == TK_KLOP;
+    u64 p0 = seat_cards(g, 0) & g.C, p1 = seat_cards(g, 1) & g.C;
+    u64 p2 = seat_cards(g, 2) & g.C, p3 = seat_cards(g, 3) & g.C;
+    u64 t = ((g.team & 1) ? p0 : 0) | ((g.team & 2) ? p1 : 0) | ((g.team & 4) ? p2 : 0) | ((g.team & 8) ? p3 : 0);
     u64 kingbit = 1ULL << (g.king * 8 + 7);
-    bool alone_with_king = g.contract != TK_SOLO_BREZ && __popc(g.team) == 1 && has_king(g.contract) &&
-                           (seat_cards(g, g.declarer) & won & kingbit);   // Navadna_igra.py:87
-    if (alone_with_king) t |= rest;
-    int v = prestej(t), d = v - 35, ad = d < 0 ? -d : d;
-    int r = 5 * ((ad + 2) / 5);                                          // int(round(d/5))*5, :103
+    u64 pd = seat_cards(g, g.declarer) & g.C;
+    bool alone_with_king = !klop && g.contract != TK_SOLO_BREZ && __popc(g.team) == 1 && has_king(g.contract) &&
+                           (pd & kingbit);                                // Navadna_igra.py:87
+    if (alone_with_king) t |= talon_unowned(g);
+    int c0 = prestej(klop ? p0 : t), c1 = prestej(klop ? p1 : 0), c2 = prestej(klop ? p2 : 0), c3 = prestej(klop ? p3 : 0);
+    bool over = c0 > 35 || c1 > 35 || c2 > 35 || c3 > 35;
+    int d = c0 - 35, ad = d < 0 ? -d : d;
+    int r = 5 * (int)(((u32)(ad + 2) * 205u) >> 10);                     // int(round(d/5))*5, :103
     if (d < 0) r = -r;
     int c = 10 * (int)g.contract;
-    int sc = (v > 35 ? c : -c) + r;
-    return pack_scores((g.team & 1) ? sc : 0, (g.team & 2) ? sc : 0, (g.team & 4) ? sc : 0, (g.team & 8) ? sc : 0);
+    int sc = (c0 > 35 ? c : -c) + r;
+    int s0 = klop ? (over ? 0 : -c0) : ((g.team & 1) ? sc : 0);
+    int s1 = klop ? (over ? 0 : -c1) : ((g.team & 2) ? sc : 0);
+    int s2 = klop ? (over ? 0 : -c2) : ((g.team & 4) ? sc : 0);
+    int s3 = klop ? (over ? 0 : -c3) : ((g.team & 8) ? sc : 0);
+    return pack_scores(s0, s1, s2, s3);
 }
 
 // One card: the body of krog (Klop.py:47-79, Navadna_igra.py:115-141) after
@@ -212,7 +218,7 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores) {
         return 1;
     }
     if (g.trick_no < 12) return 0;
-    scores = g.contract == TK_KLOP ? score_klop(g) : score_navadna(g);
+    scores = score_game(g);
     g.phase = TK_PHASE_DONE;
     return 1;
 }
@@ -223,7 +229,8 @@ __device__ __forceinline__ void setup_game(Game &g, u64 h0, u64 h1, u64 h2, u64 
                                            u32 contract, u32 declarer, u32 king) {
     g.A = h1 | h3; g.B = h2 | h3;
     g.talon = talon36;
-    g.C = ids_mask(talon36, 0, 6);
+    u64 tal = ids_mask(talon36, 0, 6);
+    g.C = tal;
     g.trick = 0; g.nt = 0; g.trick_no = 0; g.error = 0;
     g.contract = contract; g.declarer = declarer;
     g.king = has_king(contract) ? king : 0;
@@ -239,6 +246,12 @@ __device__ __forceinline__ void setup_game(Game &g, u64 h0, u64 h1, u64 h2, u64 
         }
         g.team = team;
         g.tl = (has_exchange(contract) || contract == TK_SOLO_BREZ) ? 7 : 0;
+        // Park the un-owned talon in the pile bits of the lowest seat OUTSIDE the team: whatever
+        // of it is never picked up ends with the opponents (Navadna_igra.py:87-92) except in
+        // the alone-with-king case, which score_game handles.
+        u32 o = (u32)__builtin_ctz(~team & 15u);
+        g.A |= (o & 1) ? tal : 0;
+        g.B |= (o & 2) ? tal : 0;
     }
     g.phase = has_exchange(contract) ? TK_PHASE_EXCHANGE : TK_PHASE_PLAY;
 }

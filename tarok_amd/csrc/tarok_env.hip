@@ -22,8 +22,9 @@
 struct __attribute__((aligned(64))) Aux {
     ulonglong2 n01, n23;   // the slot's NEXT game, dealt ahead by k_prefetch (phase bits 0 = not ready)
     int4 score_sum;        // scores summed over finished games, by seat (Tarok.rezultati)
+    u64 nkey;              // RNG key of that next game
     u32 episode;           // episode number of the slot's current game
-    u32 pad[3];
+    u32 pad;
 };
 
 struct tarok_env {
@@ -35,6 +36,7 @@ struct tarok_env {
     Aux *aux;                // finish-path record per slot
     uint8_t *nstale;         // 1 = next-game buffer empty (what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
+    u64 *stamps;             // diagnostics only: per-wave {realtime start, realtime end, cycles} of the last k_step
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
     hipGraphExec_t gexec;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
         pack(g, a.x, a.y, b.x, b.y);
         aux[i].n23 = b;
         aux[i].n01 = a;
+        aux[i].nkey = key;
         nstale[i] = 0;
     }
 }
@@ -211,9 +214,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
     int16_t *__restrict__ reward, uint8_t *__restrict__ done, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u64 *__restrict__ stamps) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
+    u64 t_real0 = 0, t_cyc0 = 0;
+    if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
     int64_t ic = valid ? i : n - 1;
     Game g;
     load_game(g, s01, s23, ic);
@@ -231,8 +236,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     int4 acc = make_int4(0, 0, 0, 0);
     ulonglong2 na = make_ulonglong2(0, 0), nb = na;
     u32 cur_ep = 0;
+    u64 nkey = 0;
     if (may_end) acc = aux[i].score_sum;
-    if (may_renew) { na = aux[i].n01; nb = aux[i].n23; cur_ep = aux[i].episode; }
+    if (may_renew) { na = aux[i].n01; nb = aux[i].n23; nkey = aux[i].nkey; cur_ep = aux[i].episode; }
     if (RANDOM) {
         if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
         if (action_out && valid) action_out[i] = (uint8_t)a;
@@ -254,12 +260,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
         // for >= 4 steps) the wave deals it cooperatively right here.
         renew = valid && g.phase == TK_PHASE_DONE;
         if (__ballot(renew)) {
-            u64 nkey = 0;
-            u32 nep = 0;
+            u32 nep = cur_ep + 1;
             bool swapped = false;
             if (renew) {
-                nep = cur_ep + 1;
-                nkey = game_key(seed, offset + (u64)i, nep);
                 if ((na.x >> 62) != 0) {
                     unpack(g, na.x, na.y, nb.x, nb.y);
                     aux[i].n01.x = 0;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
             bool deal_here = renew && !swapped;
             u64 pend = __ballot(deal_here);
             if (pend) {
+                if (deal_here) nkey = game_key(seed, offset + (u64)i, nep);
                 u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
                 u32 lane = __lane_id();
                 while (pend) {
@@ -295,6 +299,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
         if (res != -2 || renew) store_game(g, s01, s23, i);
         obs[i] = obs_word(g, fin);
         if (done) done[i] = fin ? 1 : 0;
+    }
+    if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics: never set in bench/test runs
+        u64 w = ((u64)blockIdx.x * TK_BLOCK + threadIdx.x) >> 6;
+        stamps[3 * w + 0] = t_real0;
+        stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[3 * w + 2] = __builtin_amdgcn_s_memtime() - t_cyc0;
     }
 }
 
@@ -488,11 +498,11 @@ static inline void launch_step(tarok_env *e, bool random, const uint8_t *action,
     if (random)
         hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
                            flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
-                           e->gkey);
+                           e->gkey, e->stamps);
     else
         hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
                            flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
-                           e->gkey);
+                           e->gkey, e->stamps);
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
@@ -580,6 +590,13 @@ int tarok_rollout_random(tarok_env *e, uint32_t episode, int16_t *scores_out, in
     hipLaunchKernelGGL(k_rollout, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
                        episode, e->mix, scores_out, nsteps_out, seats_out, (u64 *)masks_out, actions_out);
     HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_debug_stamps(tarok_env *e, uint64_t *stamps) {
+    if (!e) return TAROK_EINVAL;
+    e->stamps = (u64 *)stamps;
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     return TAROK_OK;
 }
 
