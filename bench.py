@@ -157,8 +157,17 @@ def main():
         k_us = ev_ms * 1e3 / args.steps
         algo_bytes = ALGO_BYTES_PER_STEP * n
         achieved = algo_bytes / (k_us * 1e-6) / 1e9
+        # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this same
+        # command (counters cannot be read from inside the process): FETCH_SIZE x2 + WRITE_SIZE
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_65536.json")
+        if n == 65536 and os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("k_step_true_traffic_bytes_per_launch")
+            traffic_src = "profiles/r01_pmc_fetch_write_65536.json"
         out["roofline"] = {"bound": "hbm", "kernel": "k_step<true> (tarok_step_random)", "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us,
                            "note": "54 B/step (SURVEY 8d) x %d games per launch / (HIP-event time of the timed region / "
                                    "launches); at this N the per-GPU state (2 MB) is cache resident and the launch is "

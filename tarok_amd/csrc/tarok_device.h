@@ -1,18 +1,20 @@
 // Device-side Tarok rules on bit-packed per-game lanes (gfx950 / CDNA4 only).
 //
-// One game = 4 x uint64 ("packed lanes"), kept in two 16-byte SoA arrays so a
-// wave reads/writes 1 KiB contiguous per instruction:
+// One game = 4 x uint64, kept as two 16-byte pairs in two SoA arrays so a wave
+// reads/writes 1 KiB contiguous per instruction:
 //
-//   L0 = A plane [53:0] | n_in_trick<<54 (2) | leader<<56 (2) | trick_no<<58 (4) | phase<<62 (2)
-//   L1 = B plane [53:0] | contract<<54 (4)   | declarer<<58 (2) | king<<60 (2)   | error<<62 (1)
-//   L2 = C plane [53:0] | team<<54 (4)       | tl<<58 (3)
-//   L3 = talon 6x6 bit ids [35:0] | current trick 4x6 bit ids [59:36]
+//   play pair (rewritten by every card)
+//     X0 = C plane [53:0] | n_in_trick<<54 (2) | leader<<56 (2) | trick_no<<58 (4) | phase<<62 (2)
+//     X1 = talon 6x6-bit ids [35:0] | current trick 4x6-bit ids [59:36] | tl<<60 (3) | error<<63
+//   seat pair (rewritten only when a trick is resolved: every 4th card)
+//     Y0 = A plane [53:0] | contract<<54 (4) | declarer<<58 (2) | king<<60 (2)
+//     Y1 = B plane [53:0] | team<<54 (4)
 //
 // Card c (bit c of every plane) belongs to seat (B_c A_c).  C_c = 0: it is in
 // that seat's hand (Igralec.roka).  C_c = 1: it has left the hands — it lies in
 // that seat's won pile (Igralec.kupcek), or on the table (attributed to whoever
 // played it until the trick is resolved), or it is a talon card nobody owns yet
-// (seat bits 0; told apart through the ordered talon ids in L3).
+// (parked in an opponent's pile bits; told apart through the ordered talon ids).
 // `tl` is Klop's len(self.talon) (Klop.py:67) or, for Tri..Solo_ena, the chosen
 // talon group (7 = none yet).
 //
@@ -46,21 +48,29 @@ struct Game {
     u32 trick, nt, leader, trick_no, phase, contract, declarer, king, error, team, tl;
 };
 
-__device__ __forceinline__ void unpack(Game &g, u64 l0, u64 l1, u64 l2, u64 l3) {
-    g.A = l0 & TK_DECK; g.B = l1 & TK_DECK; g.C = l2 & TK_DECK;
-    u32 m0 = (u32)(l0 >> 54), m1 = (u32)(l1 >> 54), m2 = (u32)(l2 >> 54);
+// (x0, x1) = play pair, (y0, y1) = seat pair
+__device__ __forceinline__ void unpack(Game &g, u64 x0, u64 x1, u64 y0, u64 y1) {
+    g.C = x0 & TK_DECK; g.A = y0 & TK_DECK; g.B = y1 & TK_DECK;
+    u32 m0 = (u32)(x0 >> 54), m2 = (u32)(y0 >> 54), m3 = (u32)(y1 >> 54);
     g.nt = m0 & 3; g.leader = (m0 >> 2) & 3; g.trick_no = (m0 >> 4) & 15; g.phase = m0 >> 8;
-    g.contract = m1 & 15; g.declarer = (m1 >> 4) & 3; g.king = (m1 >> 6) & 3; g.error = (m1 >> 8) & 1;
-    g.team = m2 & 15; g.tl = (m2 >> 4) & 7;
-    g.talon = l3 & ((1ULL << 36) - 1);
-    g.trick = (u32)(l3 >> 36) & 0xFFFFFF;
+    g.talon = x1 & ((1ULL << 36) - 1);
+    g.trick = (u32)(x1 >> 36) & 0xFFFFFF;
+    g.tl = (u32)(x1 >> 60) & 7; g.error = (u32)(x1 >> 63);
+    g.contract = m2 & 15; g.declarer = (m2 >> 4) & 3; g.king = (m2 >> 6) & 3;
+    g.team = m3 & 15;
 }
 
-__device__ __forceinline__ void pack(const Game &g, u64 &l0, u64 &l1, u64 &l2, u64 &l3) {
-    l0 = g.A | ((u64)(g.nt | (g.leader << 2) | (g.trick_no << 4) | (g.phase << 8)) << 54);
-    l1 = g.B | ((u64)(g.contract | (g.declarer << 4) | (g.king << 6) | (g.error << 8)) << 54);
-    l2 = g.C | ((u64)(g.team | (g.tl << 4)) << 54);
-    l3 = g.talon | ((u64)g.trick << 36);
+__device__ __forceinline__ void pack_play(const Game &g, u64 &x0, u64 &x1) {
+    x0 = g.C | ((u64)(g.nt | (g.leader << 2) | (g.trick_no << 4) | (g.phase << 8)) << 54);
+    x1 = g.talon | ((u64)g.trick << 36) | ((u64)g.tl << 60) | ((u64)g.error << 63);
+}
+__device__ __forceinline__ void pack_seats(const Game &g, u64 &y0, u64 &y1) {
+    y0 = g.A | ((u64)(g.contract | (g.declarer << 4) | (g.king << 6)) << 54);
+    y1 = g.B | ((u64)g.team << 54);
+}
+__device__ __forceinline__ void pack(const Game &g, u64 &x0, u64 &x1, u64 &y0, u64 &y1) {
+    pack_play(g, x0, x1);
+    pack_seats(g, y0, y1);
 }
 
 __device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }

@@ -2,8 +2,8 @@
 //
 // One thread per game, 256-thread workgroups (4 waves).  Per-game state is the
 // 4 packed uint64 lanes of tarok_device.h, stored as two 16-byte SoA arrays
-// (s01[g] = {L0,L1}, s23[g] = {L2,L3}): every wave-level load/store moves
-// 1 KiB contiguous.  The work is integer mask algebra + popcounts bounded by
+// (s01[g] = play pair {X0,X1}, s23[g] = seat pair {Y0,Y1}): every wave-level
+// load/store moves 1 KiB contiguous.  The work is integer mask algebra + popcounts bounded by
 // HBM bandwidth (no MFMA); the only cross-lane work is the wave-cooperative
 // re-deal of the few games per wave that finish in a step.
 #include "tarok_device.h"
@@ -20,7 +20,8 @@
 // (its score sums, episode number and the prefetched next game) sits together,
 // so the sparse finish path costs one line instead of four.
 struct __attribute__((aligned(64))) Aux {
-    ulonglong2 n01, n23;   // the slot's NEXT game, dealt ahead by k_prefetch (phase bits 0 = not ready)
+    ulonglong2 n01, n23;   // the slot's NEXT game (play pair, seat pair), dealt ahead by k_prefetch;
+                           // phase bits of n01.x == 0: not ready
     int4 score_sum;        // scores summed over finished games, by seat (Tarok.rezultati)
     u64 nkey;              // RNG key of that next game
     u32 episode;           // episode number of the slot's current game
@@ -61,10 +62,17 @@ __device__ __forceinline__ void load_game(Game &g, const ulonglong2 *s01, const 
     ulonglong2 a = s01[i], b = s23[i];
     unpack(g, a.x, a.y, b.x, b.y);
 }
-__device__ __forceinline__ void store_game(const Game &g, ulonglong2 *s01, ulonglong2 *s23, int64_t i) {
-    ulonglong2 a, b;
-    pack(g, a.x, a.y, b.x, b.y);
-    s01[i] = a; s23[i] = b;
+// the play pair always; the seat pair only when the A/B planes (or the setup fields) changed
+__device__ __forceinline__ void store_game(const Game &g, ulonglong2 *s01, ulonglong2 *s23, int64_t i,
+                                           bool seats_changed = true) {
+    ulonglong2 a;
+    pack_play(g, a.x, a.y);
+    s01[i] = a;
+    if (seats_changed) {
+        ulonglong2 b;
+        pack_seats(g, b.x, b.y);
+        s23[i] = b;
+    }
 }
 
 // Igra.razdeli + engine construction + talon exchange for every slot.
@@ -296,7 +304,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
         }
     }
     if (valid) {
-        if (res != -2 || renew) store_game(g, s01, s23, i);
+        // A/B change only when a trick was resolved (n_in_trick wrapped to 0) or a new game came in
+        if (res != -2 || renew) store_game(g, s01, s23, i, renew || (res >= 0 && g.nt == 0));
         obs[i] = obs_word(g, fin);
         if (done) done[i] = fin ? 1 : 0;
     }
