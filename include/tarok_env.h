@@ -46,6 +46,8 @@ extern "C" {
 /* synthetic contract mixes used when tarok_reset gets contract == NULL */
 #define TAROK_MIX_ALL 0      /* 1/3 Klop, 1/3 Berac (1/2 open), 1/3 Navadna+Solo over 7 types */
 #define TAROK_MIX_NAVADNA3 1 /* Tri / Dve / Ena uniform                                       */
+#define TAROK_MIX_BOT 2      /* a bidding round between four Bot players decides (Igra.py:75-114,  */
+                             /* Igralec.py:148-156): the reference's own contract distribution    */
 #define TAROK_MIX_FIXED 16   /* TAROK_MIX_FIXED + code: every game plays that contract         */
 
 /* flags */
@@ -123,12 +125,16 @@ int tarok_legal_actions(tarok_env *env, uint64_t *obs_out, int8_t *seat_out, voi
  *   reward_out [N,4] i16 scores by seat (`pisejo`): written ONLY for games that
  *              finish in this step; may be NULL
  *   done_out   [N] u8 1 iff the game finished in this step; may be NULL
+ *   trick_out  [N] u16, may be NULL: what rezultat_stiha(stih, sem_pobral) is told
+ *              (Klop.py:76-77, Navadna_igra.py:138-139).  0 unless this step completed a
+ *              trick; then 0x8000 | Roka.vrednost_stiha(stih) << 4 | seat that took it
+ *              (Roka.py:76-95; stih = the 4 cards, 5 with Klop's talon card)
  *   obs_out    [N] u64 observation for the NEXT move (see TAROK_OBS_*)
  *   flags      TAROK_AUTO_RESET: a game that finishes is re-dealt at once
  *              (episode+1, synthetic contract, Bot exchange); obs_out then
  *              describes the new game and keeps TAROK_OBS_DONE set. */
 int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8_t *done_out,
-               uint64_t *obs_out, int flags, void *stream);
+               uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
 /* Deal, ahead of time, the next game (episode+1, synthetic contract, Bot
  * exchange) of every slot whose next-game buffer is empty.  With it a
@@ -145,7 +151,7 @@ int tarok_policy_random(tarok_env *env, const uint64_t *obs, uint8_t *action_out
 
 /* tarok_policy_random + tarok_step fused in one launch; action_out may be NULL. */
 int tarok_step_random(tarok_env *env, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out,
-                      uint64_t *obs_out, int flags, void *stream);
+                      uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
 /* n_steps lock-steps of the random policy, launched from C (optionally as a
  * replayed hipGraph of `graph_chunk` steps; 0 = eager launches).

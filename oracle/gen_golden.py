@@ -150,7 +150,7 @@ class TracePlayer:
 
     def rezultat_stiha(self, stih, sem_pobral, id_igre):
         if sem_pobral:
-            self.ctl.on_trick(self, id_igre, [k.v_id() for k in stih])
+            self.ctl.on_trick(self, id_igre, [k.v_id() for k in stih], REF["Roka"].Roka.vrednost_stiha(stih))
 
     def rezultat_igre(self, st_tock, povzetek_igre, id_igre):
         self.ctl.on_result(self, id_igre, st_tock)
@@ -200,8 +200,8 @@ class Recorder:
         self.actions.append(a)
         return a
 
-    def on_trick(self, p, gid, ids):
-        self.tricks.append((p.seat[gid], ids))
+    def on_trick(self, p, gid, ids, value=0):
+        self.tricks.append((p.seat[gid], ids, int(value)))
 
     def on_result(self, p, gid, pts):
         self.scores[p.seat[gid]] = int(pts)
@@ -251,7 +251,7 @@ def run_reference_game(perm, contract, declarer, king, group_fn, discard_fn, car
     hands_end = [cards_mask(p.roka[0]) for p in players]
     return dict(seats=rec.seats, masks=rec.masks, actions=rec.actions, scores=scores,
                 piles=piles, hands_end=hands_end, hands0=rec.hands0,
-                choice=rec.choice, discards=rec.discards)
+                choice=rec.choice, discards=rec.discards, tricks=rec.tricks)
 
 
 def igra_reachable(contract, declarer):
@@ -275,6 +275,7 @@ def pack_games(games):
         masks=np.zeros((G, 48), np.uint64), actions=np.full((G, 48), 255, np.uint8),
         scores=np.zeros((G, 4), np.int16), piles=np.zeros((G, 4), np.uint64),
         hands_end=np.zeros((G, 4), np.uint64), flow=np.zeros(G, np.uint8),
+        trick_winner=np.full((G, 12), -1, np.int8), trick_value=np.full((G, 12), -1, np.int8),
     )
     for i, g in enumerate(games):
         out["deals"][i] = g["perm"]
@@ -293,6 +294,9 @@ def pack_games(games):
         out["piles"][i] = np.array(g["piles"], dtype=np.uint64)
         out["hands_end"][i] = np.array(g["hands_end"], dtype=np.uint64)
         out["flow"][i] = 1 if g["flow"] == "igra" else 0
+        for j, (w, ids, val) in enumerate(g["tricks"]):
+            out["trick_winner"][i, j] = w          # rezultat_stiha(sem_pobral=True) seat
+            out["trick_value"][i, j] = val         # Roka.vrednost_stiha(stih), Roka.py:76-95
     return out
 
 
@@ -467,7 +471,7 @@ class ParalelCtl:
         self.steps[gid] = t + 1
         return S.policy_action(self.key(gid), t, mask)
 
-    def on_trick(self, *a):
+    def on_trick(self, *a, **k):
         pass
 
     def on_result(self, p, gid, pts):
@@ -586,7 +590,8 @@ def main():
            "micro": micro_vectors(), "synthetic": []}
     runs = [dict(name="config2_navadna3_4096", seed=0, n=4096, episode=0, mix=S.MIX_NAVADNA3),
             dict(name="mixed_4096_seed1", seed=1, n=4096, episode=0, mix=S.MIX_ALL),
-            dict(name="mixed_2048_seed2_ep3", seed=2, n=2048, episode=3, mix=S.MIX_ALL)]
+            dict(name="mixed_2048_seed2_ep3", seed=2, n=2048, episode=3, mix=S.MIX_ALL),
+            dict(name="bot_bidding_4096_seed4", seed=4, n=4096, episode=0, mix=S.MIX_BOT)]
     if not args.skip_large:
         runs.append(dict(name="config3_mixed_65536", seed=0, n=65536, episode=0, mix=S.MIX_ALL))
     for r in runs:

@@ -18,7 +18,7 @@ class ToGame(C.Structure):
         ("n_in_trick", C.c_uint8), ("leader", C.c_uint8), ("trick_no", C.c_uint8),
         ("contract", C.c_uint8), ("declarer", C.c_uint8), ("king", C.c_int8),
         ("team", C.c_uint8), ("talon_left", C.c_uint8), ("choice", C.c_int8),
-        ("phase", C.c_uint8), ("error", C.c_uint8), ("score", C.c_int16 * 4),
+        ("phase", C.c_uint8), ("error", C.c_uint8), ("score", C.c_int16 * 4), ("last_trick", C.c_uint16),
     ]
 
 
@@ -45,6 +45,7 @@ def lib():
     L.to_discardable.restype = u64; L.to_discardable.argtypes = [u64]
     L.to_legal_navadna.restype = u64; L.to_legal_navadna.argtypes = [u64, i32]
     L.to_legal_klop.restype = u64; L.to_legal_klop.argtypes = [u64, i32]
+    L.to_vrednost_stiha.restype = i32; L.to_vrednost_stiha.argtypes = [u64, i32]
     L.to_trick_winner.restype = i32; L.to_trick_winner.argtypes = [P(C.c_uint8)]
     L.to_new_game.restype = None; L.to_new_game.argtypes = [P(ToGame), P(C.c_uint8), i32, i32, i32]
     L.to_exchange.restype = i32; L.to_exchange.argtypes = [P(ToGame), i32, P(C.c_uint8)]
@@ -56,6 +57,7 @@ def lib():
     L.to_rng32.restype = u32; L.to_rng32.argtypes = [u64, u32]
     L.to_deal_perm.restype = None; L.to_deal_perm.argtypes = [u64, P(C.c_uint8)]
     L.to_sample_setup.restype = None; L.to_sample_setup.argtypes = [u64, i32, P(i32), P(i32), P(i32)]
+    L.to_bot_bidding.restype = None; L.to_bot_bidding.argtypes = [u64, P(i32), P(i32)]
     L.to_bot_discards.restype = None; L.to_bot_discards.argtypes = [u64, u64, i32, P(C.c_uint8)]
     L.to_policy_action.restype = i32; L.to_policy_action.argtypes = [u64, i32, u64]
     L.to_synth_game.restype = None; L.to_synth_game.argtypes = [P(ToGame), u64, u64, u64, i32]

@@ -50,6 +50,12 @@ int to_prestej(uint64_t pile) {
     return v - 2 * (n / 3) - (n % 3 != 0);
 }
 
+/* Roka.vrednost_stiha (Roka.py:76-95) of one trick given as a mask of n_cards cards */
+int to_vrednost_stiha(uint64_t stih, int n_cards) {
+    int v = popc(stih) + 4 * popc(stih & V5) + 3 * popc(stih & V4) + 2 * popc(stih & V3) + popc(stih & V2);
+    return (n_cards == 1 || n_cards == 2) ? v - 1 : v - 2;
+}
+
 /* Navadna_igra.mozne_karte (Navadna_igra.py:158-168) */
 uint64_t to_legal_navadna(uint64_t hand, int lead) {
     if (lead >= 0) {
@@ -168,6 +174,7 @@ static void score_navadna(to_game *g) { /* Navadna_igra.py:80-113 */
 /* krog (Klop.py:47-79, Navadna_igra.py:115-141) + the per-contract start()
  * loops (Klop.py:22-45, Berac.py:13-44, Navadna_igra.py:70-113) */
 int to_step(to_game *g, int action) {
+    g->last_trick = 0;
     if (g->phase != TO_PHASE_PLAY) return -2;
     uint64_t legal = to_legal(g);
     if (action < 0 || action >= 54 || !((legal >> action) & 1)) { g->error = 1; return -1; }
@@ -179,6 +186,7 @@ int to_step(to_game *g, int action) {
     uint64_t tm = BIT(g->trick[0]) | BIT(g->trick[1]) | BIT(g->trick[2]) | BIT(g->trick[3]);
     if (g->contract == TO_KLOP && g->talon_left > 0) tm |= BIT(g->talon[--g->talon_left]); /* Klop.py:67-71 */
     g->pile[ws] |= tm;
+    g->last_trick = (uint16_t)(0x8000 | (to_vrednost_stiha(tm, popc(tm)) << 4) | ws);   /* what rezultat_stiha sees */
     g->leader = (uint8_t)ws;
     g->n_in_trick = 0;
     g->trick_no++;
@@ -260,9 +268,59 @@ void to_deal_perm(uint64_t key, uint8_t perm[54]) {
     for (int i = 0; i < 54; i++) perm[i] = (uint8_t)(k[i] & 63);
 }
 
+/* One bidding round between four Bot players: Igra.licitacija (Igra.py:75-114) with
+ * Bot_igralec.licitiram (Igralec.py:148-152) behind the base filter (Igralec.py:58-74).
+ * Bids are int(Tip_igre): Naprej -10, Klop 0, Tri 10, Dve 20, Ena 30. */
+typedef struct { uint64_t key; uint32_t calls; } bid_ctx;
+
+static int bot_ask(bid_ctx *b, int min_igra, int obvezno /* -100 = None */, int prednost) {
+    uint32_t w = pick(to_rng32(b->key, 72 + b->calls++), 6);
+    int wish = w < 3 ? -10 : (int)(w - 2) * 10;               /* Igralec.py:151 */
+    int ok = prednost ? wish >= min_igra : wish > min_igra;   /* Igralec.py:58-74 */
+    return ok ? wish : (obvezno == -100 ? -10 : obvezno);
+}
+
+void to_bot_bidding(uint64_t key, int *contract, int *declarer) {
+    bid_ctx b = {key, 0};
+    unsigned still = 0;
+    int top = 10;
+    for (int seat = 1; seat <= 3; seat++) {                   /* Igra.py:83-87 */
+        int v = bot_ask(&b, top, -100, 0);
+        if (v != -10) still |= 1u << seat;
+        if (v > top) top = v;
+    }
+    if (top == 10) {                                          /* Igra.py:89-91 */
+        *declarer = 0;
+        *contract = bot_ask(&b, -10, 0, 0) / 10;
+        return;
+    }
+    int v = bot_ask(&b, top, -100, 1);                        /* Igra.py:93-96 */
+    if (v != -10) still |= 1u;
+    if (v > top) top = v;
+    int holder = __builtin_ctz(still);                        /* min(lic), Igra.py:97 */
+    static const int order[4] = {1, 2, 3, 0};                 /* seat 0 is asked last, Igra.py:102-103 */
+    for (int rounds = 0; popc(still) != 1 && rounds < 8; rounds++) {
+        unsigned nxt = 0;
+        for (int k = 0; k < 4; k++) {
+            int seat = order[k];
+            if (!((still >> seat) & 1)) continue;
+            v = bot_ask(&b, top, seat == holder ? top : -100, 0);
+            if (v != -10) { nxt |= 1u << seat; holder = seat; top = v; }
+        }
+        still = nxt;
+    }
+    *declarer = holder;
+    *contract = top / 10;
+}
+
 void to_sample_setup(uint64_t key, int mix, int *contract, int *declarer, int *king) {
     static const int nav7[7] = {TO_TRI, TO_DVE, TO_ENA, TO_SOLO_TRI, TO_SOLO_DVE, TO_SOLO_ENA, TO_SOLO_BREZ};
     int c;
+    if (mix == TO_MIX_BOT) {
+        to_bot_bidding(key, contract, declarer);
+        *king = (*contract >= TO_TRI && *contract <= TO_ENA) ? (int)pick(to_rng32(key, 67), 4) : -1;
+        return;
+    }
     if (mix >= TO_MIX_FIXED) c = mix - TO_MIX_FIXED;
     else if (mix == TO_MIX_NAVADNA3) c = TO_TRI + (int)pick(to_rng32(key, 65), 3);
     else {

@@ -50,6 +50,7 @@ N_DISCARD = [0, 3, 2, 1, 3, 2, 1, 0, 0, 0]     # Navadna_igra.py:48-57
 # mix modes (tarok_env.h TAROK_MIX_*)
 MIX_ALL = 0          # config 3: 1/3 Klop, 1/3 Berac (1/2 open), 1/3 Navadna/Solo over 7 types
 MIX_NAVADNA3 = 1     # config 2: Tri/Dve/Ena uniform
+MIX_BOT = 2          # contracts come out of a bidding round between four Bot players (Igra.py:75-114, Igralec.py:148-156)
 MIX_FIXED = 16       # MIX_FIXED + code: every game plays that contract
 
 # RNG draw indices
@@ -59,6 +60,8 @@ DRAW_TYPE = 65
 DRAW_DECLARER = 66
 DRAW_KING = 67
 DRAW_DISCARD = 68    # 68..70
+DRAW_BID = 72        # 72 + n: the n-th licitiram call of the game's bidding round (MIX_BOT)
+BID_ROUND_CAP = 8    # the re-bidding loop (Igra.py:98-113) is cut after 8 rounds: the holder plays
 DRAW_POLICY = 128    # 128 + step
 
 
@@ -118,8 +121,57 @@ def deal(key):
     return [k & 63 for k in keys]
 
 
+def bot_wish(r):
+    """Bot_igralec's wish (Igralec.py:151): Naprej 1/2, Tri / Dve / Ena 1/6 each, as int(Tip_igre)."""
+    w = pick(r, 6)
+    return -10 if w < 3 else (w - 2) * 10
+
+
+def bot_bidding(key):
+    """One bidding round between four Bots, straight-line restatement of Igra.licitacija
+    (Igra.py:75-114) with the player-side filter (Igralec.py:58-74); the n-th licitiram
+    call consumes draw DRAW_BID + n.  Returns (declarer seat, contract code)."""
+    calls = [0]
+
+    def ask(min_igra, obvezno, prednost):
+        wish = bot_wish(rng32(key, DRAW_BID + calls[0]))
+        calls[0] += 1
+        ok = wish >= min_igra if prednost else wish > min_igra
+        return wish if ok else (-10 if obvezno is None else obvezno)
+
+    still, top = 0, 10
+    for seat in (1, 2, 3):
+        b = ask(top, None, False)
+        if b != -10:
+            still |= 1 << seat
+        top = max(top, b)
+    if top == 10:
+        return 0, ask(-10, 0, False) // 10
+    b = ask(top, None, True)
+    if b != -10:
+        still |= 1
+    top = max(top, b)
+    holder = min(i for i in range(4) if (still >> i) & 1)
+    rounds = 0
+    while popcount(still) != 1 and rounds < BID_ROUND_CAP:
+        rounds += 1
+        nxt = 0
+        for seat in (1, 2, 3, 0):
+            if (still >> seat) & 1:
+                b = ask(top, top if seat == holder else None, False)
+                if b != -10:
+                    nxt |= 1 << seat
+                    holder, top = seat, b
+        still = nxt
+    return holder, top // 10
+
+
 def sample_setup(key, mix):
     """(contract, declarer, king_suit) for one synthetic game."""
+    if mix == MIX_BOT:
+        declarer, contract = bot_bidding(key)
+        king = pick(rng32(key, DRAW_KING), 4) if contract in (TRI, DVE, ENA) else -1
+        return contract, declarer, king
     if mix >= MIX_FIXED:
         contract = mix - MIX_FIXED
     elif mix == MIX_NAVADNA3:

@@ -94,10 +94,10 @@ def lib():
     L.tarok_reset.restype = i32; L.tarok_reset.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_exchange.restype = i32; L.tarok_exchange.argtypes = [vp, vp, vp, vp]
     L.tarok_legal_actions.restype = i32; L.tarok_legal_actions.argtypes = [vp, vp, vp, vp]
-    L.tarok_step.restype = i32; L.tarok_step.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.tarok_step.restype = i32; L.tarok_step.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_prefetch.restype = i32; L.tarok_prefetch.argtypes = [vp, vp]
     L.tarok_policy_random.restype = i32; L.tarok_policy_random.argtypes = [vp, vp, vp, vp]
-    L.tarok_step_random.restype = i32; L.tarok_step_random.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.tarok_step_random.restype = i32; L.tarok_step_random.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_run_random.restype = i32; L.tarok_run_random.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]
     L.tarok_rollout_random.restype = i32; L.tarok_rollout_random.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.tarok_get_state.restype = i32; L.tarok_get_state.argtypes = [vp, vp, vp]

@@ -187,7 +187,7 @@ __device__ __forceinline__ u64 score_game(const Game &g) {
 // (Klop.py:27-45, Berac.py:26-44, Navadna_igra.py:72-113).
 // Returns 0 = played, 1 = played and the game is finished (scores set),
 // -1 = not a legal card: nothing changes except the error bit.
-__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores) {
+__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info) {
     u64 legal = legal_now(g);
     bool ok = a < 54 && ((legal >> (a & 63)) & 1);
     g.error = ok ? g.error : 1u;     // (select, not a conditional store: keeps the struct in registers)
@@ -216,6 +216,11 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores) {
     }
     g.A = (g.A & ~tm) | ((ws & 1) ? tm : 0);
     g.B = (g.B & ~tm) | ((ws & 2) ? tm : 0);
+    // what rezultat_stiha(stih, sem_pobral) is told (Klop.py:76-77, Navadna_igra.py:138-139):
+    // Roka.vrednost_stiha of the 4 (Klop: 5) cards (Roka.py:76-95) and who took them
+    u32 tv = (u32)(popc64(tm) + popc64(tm & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + popc64(tm & (TK_V3 | TK_V4 | TK_V5)) +
+                   popc64(tm & (TK_V4 | TK_V5)) + popc64(tm & TK_V5)) - 2;
+    trick_info = 0x8000u | (tv << 4) | ws;
     g.leader = ws; g.nt = 0; g.trick = 0; g.trick_no++;
     if (g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC) {
         int v = g.contract == TK_BERAC ? 70 : 90;
@@ -339,8 +344,61 @@ __device__ __forceinline__ u32 policy_action(u64 key, u32 step, u64 mask) {
     return kth_bit(mask, pick(rng32(key, 128 + step), (u32)popc64(mask)));
 }
 
+// One bidding round between four Bot players (TAROK_MIX_BOT): the control flow of
+// Igra.licitacija (Igra.py:75-114) with Bot_igralec.licitiram (Igralec.py:148-152)
+// behind the player-side filter (Igralec.py:58-74).  Bids are int(Tip_igre)
+// (Naprej -10, Klop 0, Tri 10, Dve 20, Ena 30); the n-th licitiram call of the
+// game consumes draw 72 + n.  The re-bidding loop is cut after 8 rounds.
+struct BidCtx { u64 key; u32 calls; };
+__device__ __forceinline__ int bot_ask(BidCtx &b, int min_igra, int obvezno /* -100 = None */, bool prednost) {
+    u32 w = pick(rng32(b.key, 72 + b.calls), 6);
+    b.calls++;
+    int wish = w < 3 ? -10 : (int)(w - 2) * 10;
+    bool ok = prednost ? wish >= min_igra : wish > min_igra;
+    return ok ? wish : (obvezno == -100 ? -10 : obvezno);
+}
+__device__ __forceinline__ void bot_bidding(u64 key, u32 &contract, u32 &declarer) {
+    BidCtx b = {key, 0};
+    u32 still = 0;
+    int top = 10;
+#pragma unroll
+    for (u32 seat = 1; seat <= 3; seat++) {
+        int v = bot_ask(b, top, -100, false);
+        if (v != -10) still |= 1u << seat;
+        top = max(top, v);
+    }
+    if (top == 10) {                                 // nobody bid: seat 0 plays at least Klop
+        declarer = 0;
+        contract = (u32)(bot_ask(b, -10, 0, false) / 10);
+        return;
+    }
+    int v = bot_ask(b, top, -100, true);             // seat 0 may match (priority)
+    if (v != -10) still |= 1u;
+    top = max(top, v);
+    u32 holder = (u32)__builtin_ctz(still);
+    for (int rounds = 0; __popc(still) != 1 && rounds < 8; rounds++) {
+        u32 nxt = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            u32 seat = (k + 1) & 3;                  // 1, 2, 3, 0: seat 0 is asked last
+            if ((still >> seat) & 1) {
+                v = bot_ask(b, top, seat == holder ? top : -100, false);
+                if (v != -10) { nxt |= 1u << seat; holder = seat; top = v; }
+            }
+        }
+        still = nxt;
+    }
+    declarer = holder;
+    contract = (u32)(top / 10);
+}
+
 __device__ __forceinline__ void sample_setup(u64 key, int mix, u32 &contract, u32 &declarer, u32 &king) {
     u32 c;
+    if (mix == 2) {
+        bot_bidding(key, contract, declarer);
+        king = has_king(contract) ? pick(rng32(key, 67), 4) : 0;
+        return;
+    }
     if (mix >= 16) c = (u32)(mix - 16);
     else if (mix == 1) c = TK_TRI + pick(rng32(key, 65), 3);
     else {

@@ -220,7 +220,7 @@ template <bool RANDOM>
 __global__ __launch_bounds__(TK_BLOCK) void k_step(
     int64_t n, u64 seed, u64 offset, int mix, int flags,
     const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
-    int16_t *__restrict__ reward, uint8_t *__restrict__ done, u64 *__restrict__ obs,
+    int16_t *__restrict__ reward, uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
     uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u64 *__restrict__ stamps) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
@@ -252,9 +252,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
         if (action_out && valid) action_out[i] = (uint8_t)a;
     }
     u64 scores = 0;
+    u32 trick_info = 0;
     int res = -2;
-    if (play) res = apply_step(g, a, scores);
+    if (play) res = apply_step(g, a, scores, trick_info);
     bool fin = res == 1;
+    if (trick && valid) trick[i] = (uint16_t)trick_info;
     if (fin) {
         if (reward) reinterpret_cast<u64 *>(reward)[i] = scores;
         acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
             m = legal_now(g);
             seat = (int)((g.leader + g.nt) & 3);
             a = policy_action(key, (u32)t, m);
-            apply_step(g, a, scores);
+            u32 ti;
+            apply_step(g, a, scores, ti);
             played++;
         }
         if (seats) seats[(int64_t)t * n + i] = (int8_t)seat;
@@ -419,7 +422,7 @@ int tarok_device_count(void) {
 
 int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_offset, uint64_t seed, int mix, int flags) {
     if (!out || n_games <= 0 || n_games > (1LL << 31)) return TAROK_EINVAL;
-    if (!(mix == TAROK_MIX_ALL || mix == TAROK_MIX_NAVADNA3 || (mix >= TAROK_MIX_FIXED && mix < TAROK_MIX_FIXED + 10))) return TAROK_EINVAL;
+    if (!(mix == TAROK_MIX_ALL || mix == TAROK_MIX_NAVADNA3 || mix == TAROK_MIX_BOT || (mix >= TAROK_MIX_FIXED && mix < TAROK_MIX_FIXED + 10))) return TAROK_EINVAL;
     if (device < 0 || device >= tarok_device_count()) return TAROK_ENODEV;
     HIPCHK(hipSetDevice(device));
     tarok_env *e = new tarok_env();
@@ -503,22 +506,23 @@ int tarok_legal_actions(tarok_env *e, uint64_t *obs_out, int8_t *seat_out, void 
 }
 
 static inline void launch_step(tarok_env *e, bool random, const uint8_t *action, uint8_t *action_out,
-                               int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s) {
+                               int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s,
+                               uint16_t *trick = nullptr) {
     if (random)
         hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
+                           flags, action, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
                            e->gkey, e->stamps);
     else
         hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
+                           flags, action, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
                            e->gkey, e->stamps);
 }
 
-int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
-               int flags, void *stream) {
+int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
+               uint64_t *obs_out, int flags, void *stream) {
     if (!e || !action || !obs_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    launch_step(e, false, action, nullptr, reward_out, done_out, obs_out, flags, (hipStream_t)stream);
+    launch_step(e, false, action, nullptr, reward_out, done_out, obs_out, flags, (hipStream_t)stream, trick_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -532,11 +536,11 @@ int tarok_policy_random(tarok_env *e, const uint64_t *obs, uint8_t *action_out, 
     return TAROK_OK;
 }
 
-int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
-                      int flags, void *stream) {
+int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
+                      uint64_t *obs_out, int flags, void *stream) {
     if (!e || !obs_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    launch_step(e, true, nullptr, action_out, reward_out, done_out, obs_out, flags, (hipStream_t)stream);
+    launch_step(e, true, nullptr, action_out, reward_out, done_out, obs_out, flags, (hipStream_t)stream, trick_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

@@ -72,6 +72,7 @@ class TarokVecEnv:
             self.reward = torch.zeros((self.n, 4), dtype=torch.int16, device=self.device)
             self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             self.action = torch.full((self.n,), 255, dtype=torch.uint8, device=self.device)
+            self.trick = None     # allocated by step(..., tricks=True)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -135,12 +136,21 @@ class TarokVecEnv:
             _native.check(self.L.tarok_legal_actions(self._h, self._p(self.obs_words), None, self._stream()))
         return Obs(self.obs_words)
 
-    def step(self, action, auto_reset=False):
-        """One card per game.  Returns (Obs, reward[N,4] i16 — valid where done, done[N] u8)."""
+    def _trick_buf(self, tricks):
+        if tricks and self.trick is None:
+            with torch.cuda.device(self.device):
+                self.trick = torch.zeros(self.n, dtype=torch.int16, device=self.device)
+        return self.trick if tricks else None
+
+    def step(self, action, auto_reset=False, tricks=False):
+        """One card per game.  Returns (Obs, reward[N,4] i16 — valid where done, done[N] u8).
+        tricks=True also fills self.trick [N] i16: 0, or 0x8000 | vrednost_stiha<<4 | winner seat
+        for games whose trick this card completed (what rezultat_stiha is told)."""
         a = self._dev(action, torch.uint8, (self.n,))
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_step(self._h, self._p(a), self._p(self.reward), self._p(self.done),
-                                            self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0, self._stream()))
+                                            self._p(self._trick_buf(tricks)), self._p(self.obs_words),
+                                            K.AUTO_RESET if auto_reset else 0, self._stream()))
         return Obs(self.obs_words), self.reward, self.done
 
     def policy_random(self, obs=None):
@@ -150,11 +160,11 @@ class TarokVecEnv:
             _native.check(self.L.tarok_policy_random(self._h, self._p(words), self._p(self.action), self._stream()))
         return self.action
 
-    def step_random(self, auto_reset=False):
+    def step_random(self, auto_reset=False, tricks=False):
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_step_random(self._h, self._p(self.action), self._p(self.reward), self._p(self.done),
-                                                   self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
-                                                   self._stream()))
+                                                   self._p(self._trick_buf(tricks)), self._p(self.obs_words),
+                                                   K.AUTO_RESET if auto_reset else 0, self._stream()))
         return Obs(self.obs_words), self.reward, self.done
 
     def prefetch(self):

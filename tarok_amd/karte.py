@@ -34,6 +34,7 @@ PAGAT, MOND, SKIS = 32, 52, 53
 # synthetic contract mixes (include/tarok_env.h TAROK_MIX_*)
 MIX_ALL = 0
 MIX_NAVADNA3 = 1
+MIX_BOT = 2
 MIX_FIXED = 16
 
 # flags (include/tarok_env.h)

@@ -84,9 +84,17 @@ def test_golden_traces_every_step(T, O, S, traces):
         assert (obs.seat.cpu().numpy()[live] == tr["seats"][live, t]).all(), t
         assert (obs.step.cpu().numpy()[live] == t).all()
         assert not obs.error.any().item()
-        obs, reward, done = env.step(tr["actions"][:, t])
+        obs, reward, done = env.step(tr["actions"][:, t], tricks=True)
         d = done.cpu().numpy().astype(bool)
         assert (d == (tr["nsteps"] == t + 1)).all(), t
+        ti = env.trick.cpu().numpy().view(np.uint16).astype(int)
+        if t % 4 == 3:      # rezultat_stiha: winner seat and Roka.vrednost_stiha(stih) from the reference run
+            k = t // 4
+            exp = 0x8000 | (tr["trick_value"][:, k].astype(int) << 4) | tr["trick_winner"][:, k].astype(int)
+            assert (ti[live] == exp[live]).all(), t
+            assert (ti[~live] == 0).all()
+        else:
+            assert (ti == 0).all()
         scores[d] = reward.cpu().numpy()[d]
         finished |= d
         assert (obs.done.cpu().numpy() == finished).all()
@@ -105,7 +113,8 @@ def test_golden_traces_every_step(T, O, S, traces):
 
 def test_device_deal_and_setup_match_oracle(T, O, S):
     """reset() with no arrays: sorting-network deal + contract mix + Bot exchange."""
-    for mix, n, seed, ep in [(S.MIX_ALL, 4096, 3, 0), (S.MIX_NAVADNA3, 1000, 4, 9), (S.MIX_FIXED + S.SOLO_DVE, 300, 5, 2)]:
+    for mix, n, seed, ep in [(S.MIX_ALL, 4096, 3, 0), (S.MIX_NAVADNA3, 1000, 4, 9), (S.MIX_FIXED + S.SOLO_DVE, 300, 5, 2),
+                             (S.MIX_BOT, 4096, 6, 1)]:
         env = T.TarokVecEnv(n, seed=seed, mix=mix, game_offset=17)
         env.reset(episode=ep)
         st = env.state()

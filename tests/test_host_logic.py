@@ -67,3 +67,29 @@ def test_base_player_filter_and_bot_bids():
     import random
     b = I.Bot_igralec("b", rng=random.Random(1))
     assert all(b.licitiram(L.TRI, 0) in (L.NAPREJ, L.DVE, L.ENA) for _ in range(50))
+
+
+def test_bot_bidding_three_statements_agree():
+    """TAROK_MIX_BOT: the host bidding round (pinned to Igra.licitacija by the fixture above)
+    driven by Bot wishes from the spec draws == the spec's straight-line form == the C oracle's."""
+    import ctypes as C
+    from oracle import oracle as O
+    from oracle import tarok_spec as S
+    Lc = O.lib()
+    hist = {}
+    for g in range(20000):
+        key = S.game_key(9, g, g % 5)
+        calls = [0]
+
+        def ask(seat, min_igra, obvezno, prednost):
+            wish = S.bot_wish(S.rng32(key, S.DRAW_BID + calls[0]))
+            calls[0] += 1
+            return L.base_filter(wish, min_igra, obvezno, prednost)
+        d, value = L.licitacija(ask)
+        assert (d, value // 10) == S.bot_bidding(key), g
+        c_, d_ = C.c_int(), C.c_int()
+        Lc.to_bot_bidding(key, C.byref(c_), C.byref(d_))
+        assert (d_.value, c_.value) == (d, value // 10), g
+        hist[value] = hist.get(value, 0) + 1
+    assert set(hist) == {0, 10, 20, 30}          # the Bot never bids above Ena (Igralec.py:151)
+    assert hist[0] > 1000 and hist[30] > hist[10]

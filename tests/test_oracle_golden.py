@@ -63,6 +63,11 @@ def replay(tr, i):
         assert g.legal() == int(tr["masks"][i, t]), (i, t)
         r = g.step(tr["actions"][i, t])
         assert r == (1 if t == n - 1 else 0), (i, t, r)
+        lt = int(g.g.last_trick)
+        if t % 4 == 3:      # what rezultat_stiha was told: (sem_pobral seat, Roka.vrednost_stiha(stih))
+            assert lt == 0x8000 | (int(tr["trick_value"][i, t // 4]) << 4) | int(tr["trick_winner"][i, t // 4]), (i, t)
+        else:
+            assert lt == 0
     assert g.done
     assert g.scores == [int(x) for x in tr["scores"][i]], i
     for s in range(4):
