@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=480)
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--graph-chunk", type=int, default=48, help="steps per replayed hipGraph (0 = eager)")
-    ap.add_argument("--prefetch-every", type=int, default=4, help="deal finished slots' next games every k steps")
+    ap.add_argument("--prefetch-every", type=int, default=8, help="deal finished slots' next games every k steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
     args = ap.parse_args()

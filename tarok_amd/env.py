@@ -172,7 +172,7 @@ class TarokVecEnv:
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_prefetch(self._h, self._stream()))
 
-    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=4):
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=8):
         """n_steps lock-steps of the random policy launched from C (optionally graph-replayed)."""
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_run_random(self._h, int(n_steps), 1 if fused else 0, int(graph_chunk),
