@@ -199,6 +199,23 @@ def main():
                                 "note": "tarok_rollout_random: whole games in registers, one launch per %d games; "
                                         "no per-step HBM state, so no HBM fraction is claimed for it" % n}
 
+        # (c) BASELINE configs 4-5: self-play with a small bf16 MLP policy (tarok_observe -> net ->
+        # masked sample -> tarok_step), PPO-style update, gradient all-reduce over RCCL when N > 1.
+        # Build-owned (the reference has no PPO): reported, never part of `value`.
+        try:
+            from tarok_amd import selfplay
+            sp = selfplay.SelfPlay(env, hidden=256, seed=0)
+            sp.iterate(T=48, epochs=1, minibatches=8)
+            st = sp.iterate(T=48, epochs=1, minibatches=8)
+            tro = sharding.max_over_ranks([st["rollout_s"], st["update_s"]])
+            out["selfplay_ppo"] = {"rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_ms_per_step": tro[0] / 48 * 1e3,
+                                   "update_ms": tro[1] * 1e3, "minibatches": 8, "allreduce_bytes_per_minibatch": st["allreduce_bytes"],
+                                   "policy": "MLP 256-256-256-(54+1), bf16 autocast", "loss": st["loss"],
+                                   "note": "env steps/s including observation kernel, policy forward and sampling"}
+            del sp
+        except Exception as ex:                      # never let the side leg break the bench line
+            out["selfplay_ppo"] = {"error": repr(ex)}
+
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(1 << 20, K.MIX_ALL)
 

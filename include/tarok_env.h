@@ -172,6 +172,24 @@ int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk
 int tarok_rollout_random(tarok_env *env, uint32_t episode, int16_t *scores_out, int16_t *nsteps_out,
                          int8_t *seats_out, uint64_t *masks_out, uint8_t *actions_out, void *stream);
 
+/* Observation features of the seat to move for a policy network: features_out [N,256] bf16,
+ * every entry 0.0 or 1.0 (feature set documented at k_observe — the build's own,
+ * the reference's encoder is part of its LSTM agent, Igralec.py:453-543):
+ *   [0,54) own hand, [54,64) contract one-hot;  [64,118) legal cards, [118,128) declarer
+ *   relative seat (4) / cards on table count (4) / on declarer's team / contract calls a king;
+ *   [128,182) cards on the table, [182,192) called-king suit (4) / trick number binary (4);
+ *   [192,246) cards already taken, [246] game live. */
+#define TAROK_OBS_FEATURES 256
+int tarok_observe(tarok_env *env, void *features_out, void *stream);
+
+/* A learned player's igraj_karto (cf. Igralec.py:344-355): sample one LEGAL card per game from
+ * policy logits.  logits [N,64] bf16 (card c in column c, columns 54..63 ignored), obs [N] the
+ * observation words (legal mask + cards played), softmax over the legal cards only, draw from the
+ * spec RNG (draw 192 + cards played).  action_out [N] u8 (255 where nothing is to be played),
+ * logp_out [N] f32 log-probability of the drawn card (may be NULL). */
+int tarok_sample_policy(tarok_env *env, const void *logits_bf16, const uint64_t *obs,
+                        uint8_t *action_out, float *logp_out, void *stream);
+
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */
 int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);

@@ -142,16 +142,33 @@ class TarokVecEnv:
                 self.trick = torch.zeros(self.n, dtype=torch.int16, device=self.device)
         return self.trick if tricks else None
 
-    def step(self, action, auto_reset=False, tricks=False):
+    def step(self, action, auto_reset=False, tricks=False, obs_out=None, reward_out=None, done_out=None):
         """One card per game.  Returns (Obs, reward[N,4] i16 — valid where done, done[N] u8).
         tricks=True also fills self.trick [N] i16: 0, or 0x8000 | vrednost_stiha<<4 | winner seat
-        for games whose trick this card completed (what rezultat_stiha is told)."""
+        for games whose trick this card completed (what rezultat_stiha is told).
+        obs_out / reward_out / done_out: caller-owned device tensors to write into instead of
+        the env's own buffers (e.g. rows of a rollout buffer)."""
         a = self._dev(action, torch.uint8, (self.n,))
+        ob = self.obs_words if obs_out is None else obs_out
+        rw = self.reward if reward_out is None else reward_out
+        dn = self.done if done_out is None else done_out
         with torch.cuda.device(self.device):
-            _native.check(self.L.tarok_step(self._h, self._p(a), self._p(self.reward), self._p(self.done),
-                                            self._p(self._trick_buf(tricks)), self._p(self.obs_words),
+            _native.check(self.L.tarok_step(self._h, self._p(a), self._p(rw), self._p(dn),
+                                            self._p(self._trick_buf(tricks)), self._p(ob),
                                             K.AUTO_RESET if auto_reset else 0, self._stream()))
-        return Obs(self.obs_words), self.reward, self.done
+        return Obs(ob), rw, dn
+
+    def sample_policy(self, logits, obs_words, action_out=None, logp_out=None):
+        """Masked categorical sample from bf16 logits [N,64] (tarok_sample_policy)."""
+        assert logits.dtype == torch.bfloat16 and logits.is_contiguous() and tuple(logits.shape) == (self.n, 64)
+        with torch.cuda.device(self.device):
+            if action_out is None:
+                action_out = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+            if logp_out is None:
+                logp_out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            _native.check(self.L.tarok_sample_policy(self._h, self._p(logits), self._p(obs_words), self._p(action_out),
+                                                     self._p(logp_out), self._stream()))
+        return action_out, logp_out
 
     def policy_random(self, obs=None):
         """Bot_igralec.igraj_karto on device (Igralec.py:158-159)."""
@@ -194,6 +211,14 @@ class TarokVecEnv:
             _native.check(self.L.tarok_rollout_random(self._h, int(episode), self._p(out["scores"]), self._p(out["nsteps"]),
                                                       self._p(out.get("seats")), self._p(out.get("masks")),
                                                       self._p(out.get("actions")), self._stream()))
+        return out
+
+    def observe(self, out=None):
+        """[N,256] bf16 features of the seat to move (include/tarok_env.h tarok_observe)."""
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((self.n, 256), dtype=torch.bfloat16, device=self.device)
+            _native.check(self.L.tarok_observe(self._h, self._p(out), self._stream()))
         return out
 
     def state(self):

@@ -1,0 +1,260 @@
+"""Self-play policy-gradient harness on top of the GPU env (BASELINE.json configs 4-5,
+SURVEY §8f row 4).  Build-owned: the reference trains a double-Q LSTM agent with
+pytorch-lightning (Igralec.py:545-714) and has no PPO, so nothing here is pinned to it —
+this exists to show the env being driven by a learner and to exercise the one collective
+of the whole build, the gradient all-reduce (RCCL over xGMI via torch.distributed).
+
+Shape of the loop (per rank, one env shard each; games need no communication):
+
+    obs  = env.observe()                        [N,256] bf16 features     (HIP kernel)
+    pi,v = net(obs)                             small MLP, bf16           (torch / rocBLAS)
+    a    = masked categorical sample            legal mask = observation word
+    env.step(a, auto_reset=True)                                          (HIP kernel)
+    ... T steps ...
+    returns: every card is credited with its seat's final score of that game (Monte-Carlo,
+    gamma = 1); clipped-surrogate PPO update; gradients summed over ranks in ONE flattened
+    all-reduce per minibatch (a few hundred KB: latency-bound, so one bucket, not many).
+"""
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import karte as K
+from . import sharding
+
+
+class PolicyNet(nn.Module):
+    """256 features -> 2 x hidden ReLU -> 54 card logits + value."""
+
+    def __init__(self, hidden=256):
+        super().__init__()
+        self.fc1 = nn.Linear(256, hidden)
+        self.fc2 = nn.Linear(hidden, hidden)
+        self.pi = nn.Linear(hidden, 64)       # 54 cards, padded to 64 outputs
+        self.v = nn.Linear(hidden, 1)
+
+    def forward_raw(self, x):
+        """(logits [N,64] incl. the 10 pad columns, value [N])."""
+        h = F.relu(self.fc1(x))
+        h = F.relu(self.fc2(h))
+        return self.pi(h), self.v(h).squeeze(-1)
+
+    def forward(self, x):
+        logits, v = self.forward_raw(x)
+        return logits[..., :54], v
+
+
+def legal_matrix(mask_words):
+    """int64 [N] observation words -> bool [N,54] legal-card matrix."""
+    bits = torch.arange(54, device=mask_words.device, dtype=torch.int64)
+    return ((mask_words.unsqueeze(-1) >> bits) & 1).bool()
+
+
+def sample_masked(logits, legal, generator=None):
+    """Sample one legal card per row.  Returns (action int64 [N], log-prob f32 [N]).
+    Rows without any legal card (finished games when auto-reset is off) get action 255."""
+    none = ~legal.any(dim=-1)
+    lg = logits.float().masked_fill(~legal, float("-inf"))
+    lg = torch.where(none.unsqueeze(-1), torch.zeros_like(lg), lg)
+    logp_all = F.log_softmax(lg, dim=-1)
+    action = torch.multinomial(logp_all.exp(), 1, generator=generator).squeeze(-1)
+    logp = logp_all.gather(-1, action.unsqueeze(-1)).squeeze(-1)
+    return torch.where(none, torch.full_like(action, 255), action), torch.where(none, torch.zeros_like(logp), logp)
+
+
+def assign_returns(done, reward, seat):
+    """Credit every transition with its seat's final score of the game it belongs to.
+
+    done [T,N] bool: the card played at t finished a game; reward [T,N,4]: scores by seat,
+    valid where done; seat [T,N]: who played at t.  Returns (ret [T,N] f32, known [T,N] bool):
+    `known` is False for the cards of games still unfinished when the rollout ends."""
+    T, N = done.shape
+    ret = torch.zeros((T, N), dtype=torch.float32, device=done.device)
+    known = torch.zeros((T, N), dtype=torch.bool, device=done.device)
+    cur = torch.zeros((N, 4), dtype=torch.float32, device=done.device)
+    have = torch.zeros(N, dtype=torch.bool, device=done.device)
+    for t in range(T - 1, -1, -1):
+        d = done[t]
+        cur = torch.where(d.unsqueeze(-1), reward[t].float(), cur)
+        have = have | d
+        ret[t] = cur.gather(-1, seat[t].long().unsqueeze(-1)).squeeze(-1)
+        known[t] = have
+    return ret, known
+
+
+def allreduce_gradients(params):
+    """Sum the gradients of `params` over all ranks in ONE flattened all-reduce and
+    average them.  No-op without an initialised process group / with one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return flat.numel() * flat.element_size()
+
+
+class SelfPlay:
+    """All four seats of every game share one policy.
+
+    The rollout is captured once into a graph (torch.cuda.graph: the library's kernels are
+    launched on torch's capture stream, so they are captured with the GEMMs) and replayed:
+    per lock-step tarok_observe -> 4 bf16 GEMMs -> tarok_sample_policy -> tarok_step, every
+    kernel reading/writing its row of static rollout buffers, no host work in between."""
+
+    def __init__(self, env, hidden=256, lr=3e-4, clip=0.2, vf_coef=0.5, ent_coef=0.01, reward_scale=1.0 / 70.0, seed=0,
+                 use_graph=True):
+        self.env = env
+        self.device = env.device
+        torch.manual_seed(seed)                       # same initial weights on every rank
+        self.net = PolicyNet(hidden).to(self.device)
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr)
+        self.clip, self.vf_coef, self.ent_coef, self.reward_scale = clip, vf_coef, ent_coef, reward_scale
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(1234 + 7919 * sharding.world()[0])
+        self.obs_words = env.reset().words.clone()
+        self.use_graph = use_graph
+        self._graph, self._buf, self._T = None, None, 0
+        self._w = None                                # bf16 copies of the weights for the rollout
+
+    def _refresh_bf16_weights(self):
+        with torch.no_grad():
+            src = [self.net.fc1.weight, self.net.fc1.bias, self.net.fc2.weight, self.net.fc2.bias,
+                   self.net.pi.weight, self.net.pi.bias, self.net.v.weight, self.net.v.bias]
+            if self._w is None:
+                self._w = [p.detach().to(torch.bfloat16).clone() for p in src]
+            else:
+                for d, p in zip(self._w, src):
+                    d.copy_(p)                        # in place: the captured graph reads these tensors
+
+    def _alloc(self, T):
+        n, dev = self.env.n, self.device
+        self._T = T
+        self._buf = dict(obs=torch.empty((T, n, 256), dtype=torch.bfloat16, device=dev),
+                         words=torch.empty((T + 1, n), dtype=torch.int64, device=dev),
+                         act=torch.empty((T, n), dtype=torch.uint8, device=dev),
+                         logp=torch.empty((T, n), dtype=torch.float32, device=dev),
+                         val=torch.empty((T, n, 1), dtype=torch.bfloat16, device=dev),
+                         done=torch.empty((T, n), dtype=torch.uint8, device=dev),
+                         reward=torch.zeros((T, n, 4), dtype=torch.int16, device=dev))   # written only where done
+        self._graph = None
+
+    def _rollout_body(self, T, prefetch_every):
+        env, buf, w = self.env, self._buf, self._w
+        for t in range(T):
+            env.observe(buf["obs"][t])
+            h = F.relu(F.linear(buf["obs"][t], w[0], w[1]))
+            h = F.relu(F.linear(h, w[2], w[3]))
+            logits = F.linear(h, w[4], w[5])
+            torch.addmm(w[7], h, w[6].t(), out=buf["val"][t])
+            env.sample_policy(logits, buf["words"][t], buf["act"][t], buf["logp"][t])
+            env.step(buf["act"][t], auto_reset=True, obs_out=buf["words"][t + 1], reward_out=buf["reward"][t],
+                     done_out=buf["done"][t])
+            if (t + 1) % prefetch_every == 0:
+                env.prefetch()
+
+    @torch.no_grad()
+    def collect(self, T, prefetch_every=8):
+        """T lock-steps of self-play into the static rollout buffers."""
+        if self._buf is None or self._T != T:
+            self._alloc(T)
+        self._refresh_bf16_weights()
+        buf = self._buf
+        buf["reward"].zero_()
+        buf["words"][0].copy_(self.obs_words)
+        if not self.use_graph:
+            self._rollout_body(T, prefetch_every)
+        else:
+            if self._graph is None:
+                # warm up outside capture (lazy library / GEMM-workspace initialisation), then restore the env
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    self._rollout_body(min(T, 2), prefetch_every)
+                torch.cuda.current_stream(self.device).wait_stream(s)
+                torch.cuda.synchronize(self.device)
+                buf["reward"].zero_()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._rollout_body(T, prefetch_every)
+                self._graph = g
+                # the capture did not execute anything; continue from the warmed-up env state
+                buf["words"][0].copy_(buf["words"][min(T, 2)])
+            self._graph.replay()
+        self.obs_words = buf["words"][T].clone()
+        return buf
+
+    def update(self, buf, epochs=2, minibatches=8):
+        """Clipped-surrogate policy-gradient update on one rollout.  Returns stats."""
+        T, n = buf["act"].shape
+        words_t = buf["words"][:T]
+        seat = (words_t >> K.OBS_SEAT_SHIFT) & 3
+        ret, known = assign_returns(buf["done"].bool(), buf["reward"], seat)
+        ret = ret * self.reward_scale
+        flat = lambda x: x.reshape(T * n, *x.shape[2:])
+        obs, words, act, logp0 = flat(buf["obs"]), flat(words_t), flat(buf["act"]).long(), flat(buf["logp"])
+        val0 = flat(buf["val"]).float().squeeze(-1)
+        ret, known = flat(ret), flat(known)
+        adv = ret - val0
+        m = known.float()
+        mean = (adv * m).sum() / m.sum().clamp(min=1)
+        std = (((adv - mean) ** 2 * m).sum() / m.sum().clamp(min=1)).sqrt().clamp(min=1e-6)
+        adv = (adv - mean) / std
+        stats = dict(loss=0.0, pi_loss=0.0, v_loss=0.0, entropy=0.0, allreduce_bytes=0, known_frac=float(m.mean()))
+        params = [p for p in self.net.parameters()]
+        count = 0
+        for _ in range(epochs):
+            perm = torch.randperm(T * n, device=self.device, generator=self.gen)
+            for idx in perm.chunk(minibatches):
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    logits, val = self.net(obs[idx])
+                legal = legal_matrix(words[idx] & K.OBS_MASK)
+                lg = logits.float().masked_fill(~legal, float("-inf"))
+                logp_all = F.log_softmax(lg, dim=-1)
+                logp = logp_all.gather(-1, act[idx].clamp(max=53).unsqueeze(-1)).squeeze(-1)
+                w = m[idx]
+                wsum = w.sum().clamp(min=1)
+                ratio = (logp - logp0[idx]).exp()
+                a = adv[idx]
+                pi_loss = -(torch.min(ratio * a, ratio.clamp(1 - self.clip, 1 + self.clip) * a) * w).sum() / wsum
+                v_loss = (((val.float() - ret[idx]) ** 2) * w).sum() / wsum
+                p = logp_all.exp()
+                ent = (-(p * torch.where(legal, logp_all, torch.zeros_like(logp_all))).sum(-1) * w).sum() / wsum
+                loss = pi_loss + self.vf_coef * v_loss - self.ent_coef * ent
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                stats["allreduce_bytes"] = allreduce_gradients(params)
+                nn.utils.clip_grad_norm_(params, 1.0)
+                self.opt.step()
+                count += 1
+                stats["loss"] += float(loss.detach())
+                stats["pi_loss"] += float(pi_loss.detach())
+                stats["v_loss"] += float(v_loss.detach())
+                stats["entropy"] += float(ent.detach())
+        for k in ("loss", "pi_loss", "v_loss", "entropy"):
+            stats[k] /= max(1, count)
+        return stats
+
+    def iterate(self, T=48, epochs=2, minibatches=8):
+        """One rollout + one update, timed.  Returns stats incl. env steps/s of the rollout."""
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        buf = self.collect(T)
+        torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        stats = self.update(buf, epochs, minibatches)
+        torch.cuda.synchronize(self.device)
+        t2 = time.perf_counter()
+        stats.update(rollout_s=t1 - t0, update_s=t2 - t1, env_steps=T * self.env.n,
+                     rollout_steps_per_s=T * self.env.n / (t1 - t0),
+                     mean_score=float(buf["reward"].float().sum() / buf["done"].float().sum().clamp(min=1) / 4),
+                     env_errors=int((buf["words"] < 0).any()))
+        return stats

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def libpath():
+    import torch  # noqa: F401  -- before any dlopen of libtarokenv.so: both must share ONE HIP runtime
     import tarok_amd
     return tarok_amd.build()
 

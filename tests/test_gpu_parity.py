@@ -407,3 +407,83 @@ def test_paralel_start_with_bot_players(T):
         assert c in (0, 10, 20, 30)             # the Bot only bids Tri/Dve/Ena (Igralec.py:151)
         assert all(len(b.roka[g]) == 0 for g, b in [(0, bots[0])])
     assert sum(rez.values()) == sum(sum(sc) for _, _, sc in t.zadnje_igre)
+
+
+def test_observe_features_match_python_restatement(T, S):
+    """tarok_observe's [N,256] bf16 rows against a plain restatement from the canonical state."""
+    n = 3000
+    env = T.TarokVecEnv(n, seed=12, mix=S.MIX_ALL)
+    obs = env.reset()
+    for t in range(13):
+        obs, _, _ = env.step(env.policy_random(obs), auto_reset=(t % 2 == 0))
+    feat = env.observe().float().cpu().numpy()
+    assert feat.shape == (n, 256) and set(np.unique(feat)) <= {0.0, 1.0}
+    st = env.state()
+    mask = obs.mask_numpy()
+    for i in range(0, n, 11):
+        meta = int(st[9, i])
+        trick = [(meta >> (6 * j)) & 63 for j in range(4)]
+        nt, leader, trick_no = (meta >> 24) & 7, (meta >> 27) & 3, (meta >> 29) & 15
+        contract, decl, king, team, phase = (meta >> 33) & 15, (meta >> 37) & 3, (meta >> 39) & 7, (meta >> 42) & 15, (meta >> 52) & 3
+        seat = (leader + nt) & 3
+        live = phase == 2
+        exp = np.zeros(256)
+
+        def put(base, m):
+            for b in range(64):
+                if (int(m) >> b) & 1:
+                    exp[base + b] = 1
+        put(0, int(st[seat, i]) | (1 << (54 + contract)))
+        put(64, int(mask[i]) | ((1 << ((decl - seat) & 3)) | (1 << (4 + nt)) | (((team >> seat) & 1) << 8) | ((1 if king != 7 else 0) << 9)) << 54)
+        table = sum(1 << trick[j] for j in range(nt))
+        put(128, table | (((1 << king) if king != 7 else 0) | (trick_no << 4)) << 54)
+        put(192, (int(st[4, i]) | int(st[5, i]) | int(st[6, i]) | int(st[7, i])) | ((1 if live else 0) << 54))
+        assert (feat[i] == exp).all(), i
+    env.close()
+
+
+def test_selfplay_iteration_runs_and_learns_something_finite(T, S):
+    import torch
+    from tarok_amd import selfplay as SP
+    env = T.TarokVecEnv(4096, seed=1, mix=S.MIX_ALL)
+    sp = SP.SelfPlay(env, hidden=128, seed=0)
+    before = [p.detach().clone() for p in sp.net.parameters()]
+    st = sp.iterate(T=48, epochs=1, minibatches=4)
+    assert np.isfinite(st["loss"]) and st["known_frac"] > 0.3 and st["rollout_steps_per_s"] > 0
+    assert st["env_errors"] == 0
+    assert any((a != b).any().item() for a, b in zip(before, sp.net.parameters()))
+    assert not env.legal_actions().error.any().item()          # the sampled cards were always legal
+    env.close()
+
+
+def test_sample_policy_kernel(T, S):
+    """tarok_sample_policy: always a legal card; log-prob equals torch's masked log-softmax;
+    draws follow the softmax (pooled chi-square-style check on identical rows)."""
+    import torch
+    from tarok_amd import selfplay as SP
+    n = 8192
+    env = T.TarokVecEnv(n, seed=3, mix=S.MIX_ALL)
+    obs = env.reset()
+    for t in range(9):
+        obs, _, _ = env.step(env.policy_random(obs), auto_reset=True)
+    words = obs.words.clone()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    logits = (torch.randn((n, 64), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    a, logp = env.sample_policy(logits, words)
+    legal = SP.legal_matrix(words & T.karte.OBS_MASK)
+    al = a.long()
+    assert legal.gather(1, al.unsqueeze(1)).all().item()
+    ref = torch.log_softmax(logits[:, :54].float().masked_fill(~legal, float("-inf")), dim=-1).gather(1, al.unsqueeze(1)).squeeze(1)
+    assert (logp - ref).abs().max().item() < 2e-3
+    # identical logits + identical legal sets in every game of a Klop opening lead -> frequencies ~ softmax
+    env2 = T.TarokVecEnv(65536, seed=5, mix=S.MIX_FIXED + S.KLOP)
+    o2 = env2.reset(deals=np.tile(np.arange(54, dtype=np.uint8), (65536, 1)), contract=np.zeros(65536, np.int8),
+                    declarer=np.zeros(65536, np.int8))
+    row = (torch.arange(64, device="cuda").float() * 0.15).to(torch.bfloat16)
+    a2, _ = env2.sample_policy(row.repeat(65536, 1).contiguous(), o2.words)
+    m = int(o2.mask_numpy()[0])
+    ids = [c for c in range(54) if (m >> c) & 1]
+    p = torch.softmax(row[:54].float()[ids], dim=0).cpu().numpy()
+    freq = np.bincount(a2.cpu().numpy(), minlength=54)[ids] / 65536.0
+    assert np.abs(freq - p).max() < 0.01
+    env.close(); env2.close()
