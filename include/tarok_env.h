@@ -196,6 +196,9 @@ int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);
 
 /* Canonical state for parity checks / checkpoints: lanes_out [10,N] u64. */
 int tarok_get_state(tarok_env *env, uint64_t *lanes_out, void *stream);
+/* Restore every game from canonical lanes (the inverse of tarok_get_state): checkpoint/resume,
+ * or hand-built positions.  The RNG keys / episode numbers / next-game buffers are untouched. */
+int tarok_set_state(tarok_env *env, const uint64_t *lanes_in, void *stream);
 /* Per-slot bookkeeping: episode_out [N] u32 (current episode number),
  * score_sum_out [N,4] i32 (scores summed over the slot's finished games =
  * Tarok.rezultati per seat, Tarok.py:59-61).  Either may be NULL. */

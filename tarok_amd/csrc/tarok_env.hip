@@ -500,6 +500,47 @@ __global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglo
     out[9 * n + i] = m;
 }
 
+// inverse of k_get_state: rebuild the packed pairs from canonical lanes (checkpoint restore,
+// hand-built positions).  Cards on the table go back to whoever played them, the un-owned
+// talon to where setup_game parks it.
+__global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__restrict__ in,
+                                                       ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 m = in[9 * n + i];
+    Game g;
+    g.trick = (u32)m & 0xFFFFFF;
+    g.nt = (u32)(m >> 24) & 7; g.leader = (u32)(m >> 27) & 3; g.trick_no = (u32)(m >> 29) & 15;
+    g.contract = (u32)(m >> 33) & 15; g.declarer = (u32)(m >> 37) & 3;
+    u32 king = (u32)(m >> 39) & 7;
+    g.king = king == 7 ? 0 : king;
+    g.team = (u32)(m >> 42) & 15;
+    u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
+    g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
+    g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
+    g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
+    u64 seatc[4];
+    u64 piles = 0;
+    for (u32 s = 0; s < 4; s++) {
+        u64 h = in[(int64_t)s * n + i] & TK_DECK, p = in[(int64_t)(4 + s) * n + i] & TK_DECK;
+        seatc[s] = h | p;
+        piles |= p;
+    }
+    u64 on_table = 0;
+    for (u32 j = 0; j < g.nt && j < 4; j++) {
+        u64 b = 1ULL << ((g.trick >> (6 * j)) & 63);
+        on_table |= b;
+        seatc[(g.leader + j) & 3] |= b;
+    }
+    u64 unowned = talon_unowned(g);                 // depends only on contract / tl / talon ids
+    u32 o = g.contract == TK_KLOP ? 0u : (u32)__builtin_ctz(~g.team & 15u);
+    seatc[o & 3] |= unowned;
+    g.A = seatc[1] | seatc[3];
+    g.B = seatc[2] | seatc[3];
+    g.C = piles | on_table | unowned;
+    store_game(g, s01, s23, i);
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -742,6 +783,15 @@ int tarok_get_state(tarok_env *e, uint64_t *lanes_out, void *stream) {
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_get_state, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23,
                        (u64 *)lanes_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_set_state(tarok_env *e, const uint64_t *lanes_in, void *stream) {
+    if (!e || !lanes_in) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_set_state, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const u64 *)lanes_in,
+                       e->s01, e->s23);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

@@ -228,6 +228,15 @@ class TarokVecEnv:
             _native.check(self.L.tarok_get_state(self._h, self._p(lanes), self._stream()))
         return _u64(lanes)
 
+    def set_state(self, lanes):
+        """Restore from canonical lanes [10,N] (numpy uint64 / int64 tensor): inverse of state()."""
+        if isinstance(lanes, np.ndarray):
+            lanes = torch.from_numpy(np.ascontiguousarray(lanes).view(np.int64))
+        lanes = self._dev(lanes, torch.int64, (10, self.n))
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_set_state(self._h, self._p(lanes), self._stream()))
+        return self.legal_actions()
+
     def counters(self):
         """(episode[N] int64, score_sum[N,4] int32) host numpy."""
         with torch.cuda.device(self.device):

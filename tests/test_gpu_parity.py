@@ -487,3 +487,99 @@ def test_sample_policy_kernel(T, S):
     freq = np.bincount(a2.cpu().numpy(), minlength=54)[ids] / 65536.0
     assert np.abs(freq - p).max() < 0.01
     env.close(); env2.close()
+
+
+def test_checkpoint_roundtrip_and_resume(T, O, S):
+    """state() -> set_state() is the identity on mid-game positions of every contract, and a
+    restored env continues exactly like the original."""
+    n = 8192
+    a = T.TarokVecEnv(n, seed=14, mix=S.MIX_ALL)
+    b = T.TarokVecEnv(n, seed=14, mix=S.MIX_ALL)
+    oa = a.reset()
+    b.reset()
+    for t in range(48):
+        if t in (0, 1, 5, 18, 31, 44, 47):
+            snap = a.state()
+            ob = b.set_state(snap)
+            assert (b.state() == snap).all(), t
+            assert (ob.words == a.legal_actions().words).all().item(), t
+            act = a.policy_random(oa).clone()
+            xa, ra, da = a.step(act)
+            xb, rb, db = b.step(act)
+            assert (xa.words == xb.words).all().item() and (da == db).all().item(), t
+            assert (ra[da.bool()] == rb[db.bool()]).all().item()
+            oa = xa
+        else:
+            oa, _, _ = a.step(a.policy_random(oa))
+    assert (a.state() == b.state()).all()          # last restore was before the final card: same end state
+    a.close(); b.close()
+
+
+def test_reference_legal_move_cases_on_device(T, golden_dir):
+    """The 600 (hand, lead) -> mozne_karte cases recorded from Klop.mozne_karte and
+    Navadna_igra.mozne_karte, run through the device legal-card kernel as hand-built positions."""
+    with open(os.path.join(golden_dir, "digests_v1.json")) as f:
+        cases = json.load(f)["micro"]["legal_cases"]
+    n = len(cases)
+    env = T.TarokVecEnv(n, seed=0)
+    for klop in (False, True):
+        lanes = np.zeros((10, n), np.uint64)
+        exp = np.zeros(n, np.uint64)
+        for i, (hand, lead, nav, klo) in enumerate(cases):
+            hand, lead = int(hand), int(lead)
+            contract = 0 if klop else 8            # Klop vs Solo_brez (no exchange, no king)
+            nt = 0 if lead < 0 else 1
+            leader = 3                             # seat 3 led; seat 0 = (3+1)&3 is to move
+            mover = (leader + nt) & 3
+            lanes[mover, i] = hand
+            rest = [c for c in range(54) if not (hand >> c) & 1 and c != lead]
+            lanes[8, i] = sum(c << (6 * j) for j, c in enumerate(rest[:6]))             # a consistent talon
+            lanes[4 + ((mover + 2) & 3), i] = sum(1 << c for c in rest[6:])             # every other card: taken
+            trick = 0 if lead < 0 else lead
+            meta = trick | (nt << 24) | (leader << 27) | (contract << 33) | (0 << 37) | (7 << 39) | ((0 if klop else 1) << 42) \
+                | ((6 if klop else 0) << 46) | (7 << 49) | (2 << 52)
+            lanes[9, i] = meta
+            exp[i] = int(klo if klop else nav)
+        obs = env.set_state(lanes)
+        assert (obs.mask_numpy() == exp).all(), klop
+    env.close()
+
+
+def test_bad_inputs_flag_only_the_offending_games(T, S, traces):
+    tr = traces
+    n = 64
+    deals = tr["deals"][:n].copy()
+    contract = np.full(n, S.KLOP, np.int8)
+    deals[3, 5] = deals[3, 6]                       # duplicate card
+    deals[7, 50] = 60                               # id out of range
+    contract[11] = 12                               # no such contract
+    env = T.TarokVecEnv(n, seed=0)
+    obs = env.reset(deals=deals, contract=contract, declarer=np.zeros(n, np.int8))
+    err = obs.error.cpu().numpy()
+    assert set(np.nonzero(err)[0]) == {3, 7, 11}
+    # a bad talon group index
+    idx = np.where((tr["contract"] == S.TRI))[0][:n]
+    env.reset(deals=tr["deals"][idx], contract=tr["contract"][idx], declarer=tr["declarer"][idx],
+              king_suit=np.maximum(tr["king"][idx], 0), defer_exchange=True)
+    ch = tr["choice"][idx].copy()
+    ch[5] = 2                                       # Tri has only groups 0 and 1
+    obs = env.exchange(talon_choice=ch, discards=tr["discards"][idx])
+    err = obs.error.cpu().numpy()
+    assert err[5] and err.sum() == 1
+    # games still waiting for the exchange ignore step() without complaint
+    before = env.state()
+    obs, _, done = env.step(np.full(n, 3, np.uint8))
+    after = env.state()
+    assert (before[:, 5] == after[:, 5]).all() and not done.cpu().numpy()[5]
+    env.close()
+
+
+def test_four_million_games_rollout_bit_exact(T, O, S):
+    """Largest parity case: 2^22 mixed games through the fused rollout kernel vs the oracle."""
+    n = 1 << 22
+    env = T.TarokVecEnv(n, seed=77, mix=S.MIX_ALL, game_offset=123456789)
+    out = env.rollout_random(episode=2)
+    ref = O.rollout(77, 123456789, n, 2, S.MIX_ALL, threads=16, trace=False)
+    assert (out["nsteps"].cpu().numpy() == ref["nsteps"]).all()
+    assert (out["scores"].cpu().numpy() == ref["scores"]).all()
+    env.close()
