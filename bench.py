@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4800)
     ap.add_argument("--warmup", type=int, default=480)
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--graph-chunk", type=int, default=48, help="steps per replayed hipGraph (0 = eager)")
+    ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--prefetch-every", type=int, default=8, help="deal finished slots' next games every k steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
@@ -97,8 +97,12 @@ def main():
     offset, _ = sharding.weak_shard(n, rank)
     env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
 
+    pf = max(1, args.prefetch_every)
+    # a graph chunk never longer than the timed region, and a multiple of the prefetch period
+    chunk = min(args.graph_chunk, (args.steps // pf) * pf) // pf * pf if args.graph_chunk > 0 else 0
+
     def run(steps, fused):
-        env.run_random(steps, fused=fused, graph_chunk=args.graph_chunk, auto_reset=True, prefetch_every=args.prefetch_every)
+        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
 
     def timed(steps, fused):
         sharding.barrier()
@@ -144,7 +148,7 @@ def main():
                    "games_per_gpu": n,
                    "mode": "tarok_step_random: 1 kernel launch per lock-step (action, observation, done, scores "
                            "materialised in HBM every step), hipGraph of %d steps, tarok_prefetch every %d steps"
-                           % (args.graph_chunk, args.prefetch_every),
+                           % (chunk, pf),
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
     }

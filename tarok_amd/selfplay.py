@@ -183,7 +183,7 @@ class SelfPlay:
                 torch.cuda.synchronize(self.device)
                 buf["reward"].zero_()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._rollout_body(T, prefetch_every)
                 self._graph = g
                 # the capture did not execute anything; continue from the warmed-up env state
