@@ -8,12 +8,14 @@ uniform-random policy, synthetic deals).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one lock-step of every game = one card played in each of the 65,536
-games of a rank (Tarok.py:48-56) = ONE launch of the step kernel: legal mask of
-the seat to move, a uniform random legal card (the Bot policy, Igralec.py:158-159),
-the card applied, trick resolution and scoring, finished games replaced at once
-(auto-reset: every slot is live in every step), next observation written.  State
-is resident in HBM between launches.  value = games x steps x ranks /
-max-over-ranks time.  Weak scaling: each rank owns its own 65,536 games
+games of a rank (Tarok.py:48-56): legal mask of the seat to move, a uniform random
+legal card (the Bot policy, Igralec.py:158-159), the card applied, trick resolution
+and scoring, finished games replaced at once (auto-reset: every slot is live in
+every step), next observation written.  One kernel launch plays one TRICK (4 such
+steps = one pass of the reference's krog generator) with the state held in
+registers in between and every per-card output written to HBM; state is resident
+in HBM between launches.  value = games x steps x ranks / max-over-ranks time.
+One-card-per-launch and the two-kernel external-policy path are reported beside it.  Weak scaling: each rank owns its own 65,536 games
 (global game indices rank*65536...), no collective in the env path.
 
 Extra objects on the JSON line:
@@ -75,6 +77,9 @@ def main():
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--prefetch-every", type=int, default=8, help="deal finished slots' next games every k steps")
+    ap.add_argument("--cards-per-launch", type=int, default=4,
+                    help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
+                         "1 = one card per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
     args = ap.parse_args()
@@ -97,36 +102,44 @@ def main():
     offset, _ = sharding.weak_shard(n, rank)
     env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
 
+    cards = max(1, args.cards_per_launch)
     pf = max(1, args.prefetch_every)
+    pf = (pf + cards - 1) // cards * cards          # the prefetch period is a whole number of launches
+    if args.steps % cards or args.warmup % cards:
+        raise SystemExit("--steps and --warmup must be multiples of --cards-per-launch (%d)" % cards)
     # a graph chunk never longer than the timed region, and a multiple of the prefetch period
     chunk = min(args.graph_chunk, (args.steps // pf) * pf) // pf * pf if args.graph_chunk > 0 else 0
 
-    def run(steps, fused):
-        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
+    def run(steps, mode):
+        """mode: 0 = policy kernel + step kernel, 1 = one card per launch, >= 2 = that many cards per launch"""
+        env.run_random(steps // max(1, mode) * max(1, mode), cards_per_launch=mode, graph_chunk=chunk, auto_reset=True,
+                       prefetch_every=pf)
 
-    def timed(steps, fused):
+    def timed(steps, mode):
         sharding.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        run(steps, fused)
+        run(steps, mode)
         torch.cuda.synchronize(dev)
         sharding.barrier()
         dt = time.perf_counter() - t0
         return sharding.max_over_ranks([dt])[0]
 
-    # ---- headline: one launch of tarok_step_random (k_step<true>: legal mask -> uniform
-    # random legal card -> apply -> trick/score -> auto-reset swap -> next observation) per
-    # lock-step, replayed as a hipGraph of `graph_chunk` steps; tarok_prefetch every
-    # `prefetch_every` steps deals the finished slots' next games.
+    # ---- headline: one launch of tarok_krog_random per trick (4 lock-steps): per card legal mask ->
+    # uniform random legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap ->
+    # next observation; state read once and written once per launch, every per-card output
+    # (action, observation word, done, scores) written to HBM.  Replayed as a hipGraph of
+    # `graph_chunk` steps; tarok_prefetch every `prefetch_every` steps deals the finished slots'
+    # next games.
     env.reset(episode=0)
-    run(args.warmup, True)
+    run(args.warmup, cards)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream = torch.cuda.current_stream(dev)
     sharding.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record(stream)
-    run(args.steps, True)
+    run(args.steps, cards)
     ev1.record(stream)
     torch.cuda.synchronize(dev)
     sharding.barrier()
@@ -146,20 +159,23 @@ def main():
                                "(1/3 Klop, 1/3 Berac incl. 1/2 open, 1/3 Navadna+Solo over 7 types), uniform random policy, "
                                "auto-reset (every slot live in every step)" % n,
                    "games_per_gpu": n,
-                   "mode": "tarok_step_random: 1 kernel launch per lock-step (action, observation, done, scores "
-                           "materialised in HBM every step), hipGraph of %d steps, tarok_prefetch every %d steps"
-                           % (chunk, pf),
+                   "mode": "tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's "
+                           "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps, "
+                           "tarok_prefetch every %d steps" % (cards, chunk, pf),
+                   "cards_per_launch": cards,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, k_step: HIP events on the launch stream around
-        # the timed region above; launch duration = region time / k_step launches (the
-        # region also holds 1 k_prefetch per `prefetch_every` steps and every launch gap, all
-        # charged to k_step -> a lower bound on its bandwidth).
-        k_us = ev_ms * 1e3 / args.steps
-        algo_bytes = ALGO_BYTES_PER_STEP * n
+        # ---- roofline of the dominant kernel (k_krog; k_step when cards = 1): HIP events on the
+        # launch stream around the timed region above; launch duration = region time / launches
+        # (the region also holds 1 k_prefetch per `prefetch_every` steps and every launch gap, all
+        # charged to the step kernel -> a lower bound on its bandwidth).  One launch processes
+        # n x cards steps, each 54 algorithmic bytes.
+        launches = args.steps // cards
+        k_us = ev_ms * 1e3 / launches
+        algo_bytes = ALGO_BYTES_PER_STEP * n * cards
         achieved = algo_bytes / (k_us * 1e-6) / 1e9
         # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this same
         # command (counters cannot be read from inside the process): FETCH_SIZE x2 + WRITE_SIZE
@@ -167,24 +183,33 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_65536.json")
         if n == 65536 and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("k_step_true_traffic_bytes_per_launch")
+                traffic = json.load(f).get("k_krog_traffic_bytes_per_launch" if cards == 4 else
+                                           ("k_step_true_traffic_bytes_per_launch" if cards == 1 else "-"))
             traffic_src = "profiles/r01_pmc_fetch_write_65536.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "k_step<true> (tarok_step_random)", "achieved": achieved,
+        out["roofline"] = {"bound": "hbm", "kernel": "k_krog (tarok_krog_random)" if cards > 1 else "k_step<true> (tarok_step_random)",
+                           "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us,
-                           "note": "54 B/step (SURVEY 8d) x %d games per launch / (HIP-event time of the timed region / "
-                                   "launches); at this N the per-GPU state (2 MB) is cache resident and the launch is "
-                                   "latency bound: see DESIGN.md for the N-sweep where HBM becomes the limiter" % n}
+                           "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us, "steps_per_launch": n * cards,
+                           "note": "54 B/step (SURVEY 8d) x %d games x %d cards per launch / (HIP-event time of the timed "
+                                   "region / launches); at this N the per-GPU state (2 MB) is cache resident and the launch "
+                                   "is latency bound: see DESIGN.md for the N-sweep where HBM becomes the limiter"
+                                   % (n, cards)}
 
     if not args.no_extras:
         # ---- side measurements (not `value`)
         # (a) the two-kernel C-ABI path: tarok_policy_random writes the action array, tarok_step consumes it
         env.reset(episode=0)
-        run(args.warmup, False)
-        dta = timed(args.steps, False)
+        run(args.warmup, 0)
+        dta = timed(args.steps, 0)
         out["api_two_kernel"] = {"value": total_steps / dta, "unit": "env steps/s", "ms_per_step": dta / args.steps * 1e3,
-                                 "note": "tarok_policy_random + tarok_step per lock-step (2 launches)"}
+                                 "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
+        # (a') one card per launch with the policy in-kernel (tarok_step_random)
+        env.reset(episode=0)
+        run(args.warmup, 1)
+        dt1 = timed(args.steps, 1)
+        out["one_card_per_launch"] = {"value": total_steps / dt1, "unit": "env steps/s", "ms_per_step": dt1 / args.steps * 1e3,
+                                      "note": "tarok_step_random: 1 launch per lock-step"}
         # (b) whole games per launch, state in registers
         sharding.barrier()
         torch.cuda.synchronize(dev)

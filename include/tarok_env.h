@@ -153,15 +153,28 @@ int tarok_policy_random(tarok_env *env, const uint64_t *obs, uint8_t *action_out
 int tarok_step_random(tarok_env *env, uint8_t *action_out, int16_t *reward_out, uint8_t *done_out,
                       uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
+/* `cards` cards of every game in one launch with the Bot policy in-kernel; cards = 4 is one trick,
+ * i.e. one pass of the reference's krog generator (Klop.py:47-79, Navadna_igra.py:115-141).
+ * The state is read once, kept in registers and written once, but every per-card output is
+ * still written: row c (c = 0..cards-1, rows `stride` >= N games apart) of action_out [cards,stride] u8,
+ * reward_out [cards,stride,4] i16 (only where done), done_out, trick_out [cards,stride] u16 and
+ * obs_out [cards,stride] u64 is what tarok_step_random would have written for the c-th card.
+ * action_out / reward_out / done_out / trick_out may be NULL.  Finished games are replaced at
+ * once with TAROK_AUTO_RESET (prefetched buffer first, then dealt in-kernel). */
+int tarok_krog_random(tarok_env *env, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,
+                      uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
+
 /* n_steps lock-steps of the random policy, launched from C (optionally as a
  * replayed hipGraph of `graph_chunk` steps; 0 = eager launches).
- * fused = 0: tarok_policy_random + tarok_step per step;  1: tarok_step_random.
+ * cards_per_launch = 0: tarok_policy_random + tarok_step per step;  1: tarok_step_random;
+ * c >= 2: tarok_krog_random(c) — n_steps, graph_chunk and prefetch_every must be multiples of c
+ * and the buffers hold c rows of N (action [c,N], reward_out [c,N,4], done_out [c,N], obs_out [c,N]).
  * prefetch_every = k > 0: tarok_prefetch after every k-th step (graph_chunk must
  * be a multiple of k); only with TAROK_AUTO_RESET.
- * Buffers as in tarok_step (action [N] u8 scratch is required for fused = 0). */
-int tarok_run_random(tarok_env *env, int64_t n_steps, int fused, int graph_chunk, int prefetch_every,
-                     uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out,
-                     int flags, void *stream);
+ * Buffers otherwise as in tarok_step (action [N] u8 scratch is required for cards_per_launch = 0). */
+int tarok_run_random(tarok_env *env, int64_t n_steps, int cards_per_launch, int graph_chunk,
+                     int prefetch_every, uint8_t *action, int16_t *reward_out, uint8_t *done_out,
+                     uint64_t *obs_out, int flags, void *stream);
 
 /* Whole games in one launch (state never leaves registers): deal + setup + Bot
  * exchange + random play to the end, for episode `episode` of every slot.

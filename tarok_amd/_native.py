@@ -18,7 +18,7 @@ SYMBOLS = [
     "tarok_strerror", "tarok_abi_version", "tarok_device_count", "tarok_last_hip_error",
     "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_reset", "tarok_exchange",
     "tarok_legal_actions", "tarok_step", "tarok_prefetch", "tarok_policy_random", "tarok_step_random",
-    "tarok_run_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy",
+    "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
     L.tarok_policy_random.restype = i32; L.tarok_policy_random.argtypes = [vp, vp, vp, vp]
     L.tarok_step_random.restype = i32; L.tarok_step_random.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_run_random.restype = i32; L.tarok_run_random.argtypes = [vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, vp]
+    L.tarok_krog_random.restype = i32; L.tarok_krog_random.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_rollout_random.restype = i32; L.tarok_rollout_random.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.tarok_get_state.restype = i32; L.tarok_get_state.argtypes = [vp, vp, vp]
     L.tarok_observe.restype = i32; L.tarok_observe.argtypes = [vp, vp, vp]

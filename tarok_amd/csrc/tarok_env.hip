@@ -319,6 +319,115 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     }
 }
 
+
+// `cards` cards of every game in ONE launch with the Bot policy evaluated in-kernel; cards = 4 is
+// one whole trick = one pass of the reference's krog generator (Klop.py:47-79,
+// Navadna_igra.py:115-141).  The packed state is read once, stays in registers while the cards
+// are played, and is written once; everything a consumer of the trajectory needs is still
+// written for EVERY card: row c of action/obs/done/trick/reward (rows are `stride` games apart)
+// belongs to the c-th card of this launch.  Per card this moves less than the one-card kernel
+// (the state traffic is shared by `cards` cards) and costs 1/cards of a launch.
+// A finished game is replaced at once: first from the prefetched buffer, after that (only
+// possible when cards > 4) by the wave-cooperative deal.
+__global__ __launch_bounds__(TK_BLOCK) void k_krog(
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride,
+    uint8_t *__restrict__ action_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
+    uint16_t *__restrict__ trick, u64 *__restrict__ obs,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    bool valid = i < n;
+    int64_t ic = valid ? i : n - 1;
+    Game g;
+    load_game(g, s01, s23, ic);
+    u64 key = gkey[ic];
+    bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
+    // lanes that can reach the end of their game within this launch (Berac: any trick end;
+    // the others: only in trick 12) issue their finish-path loads together with the state
+    bool berac = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
+    bool spec = valid && ((g.phase == TK_PHASE_PLAY && (berac || (int)(g.trick_no * 4 + g.nt) + cards >= 48)) ||
+                          g.phase == TK_PHASE_DONE);
+    int4 acc = make_int4(0, 0, 0, 0);
+    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
+    u32 cur_ep = 0;
+    u64 nkey = 0;
+    if (spec) {
+        acc = aux[i].score_sum;
+        if (autoreset) { na = aux[i].n01; nb = aux[i].n23; nkey = aux[i].nkey; cur_ep = aux[i].episode; }
+    }
+    bool have_next = (na.x >> 62) != 0;
+    bool consumed = false, renewed = false, acc_dirty = false, seats_dirty = false, touched = false;
+    for (int c = 0; c < cards; c++) {
+        bool play = valid && g.phase == TK_PHASE_PLAY;
+        u32 a = 255;
+        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
+        u64 scores = 0;
+        u32 trick_info = 0;
+        int res = -2;
+        if (play) res = apply_step(g, a, scores, trick_info);
+        bool fin = res == 1;
+        touched = touched || res != -2;
+        seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
+        int64_t row = (int64_t)c * stride + i;
+        if (valid) {
+            if (action_out) action_out[row] = (uint8_t)a;
+            if (trick) trick[row] = (uint16_t)trick_info;
+        }
+        if (fin) {
+            if (reward) reinterpret_cast<u64 *>(reward)[row] = scores;
+            acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
+            acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
+            acc_dirty = true;
+        }
+        if (autoreset) {
+            bool renew = valid && g.phase == TK_PHASE_DONE;
+            if (__ballot(renew)) {
+                bool swapped = false;
+                if (renew && have_next) {
+                    unpack(g, na.x, na.y, nb.x, nb.y);
+                    key = nkey;
+                    have_next = false; consumed = true; swapped = true;
+                }
+                bool deal_here = renew && !swapped;
+                u64 pend = __ballot(deal_here);
+                if (pend) {
+                    u64 dkey = 0;
+                    if (deal_here) dkey = game_key(seed, offset + (u64)i, cur_ep + 1);
+                    u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+                    u32 lane = __lane_id();
+                    while (pend) {
+                        int l = __builtin_ctzll(pend);
+                        pend &= pend - 1;
+                        u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)dkey, l);
+                        u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(dkey >> 32), l);
+                        u64 w0, w1, w2, w3, wt;
+                        deal_wave(klo, khi, w0, w1, w2, w3, wt);
+                        if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+                    }
+                    if (deal_here) {
+                        u32 cc, d, k;
+                        sample_setup(dkey, mix, cc, d, k);
+                        setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
+                        if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
+                        key = dkey;
+                    }
+                }
+                if (renew) { cur_ep++; renewed = true; seats_dirty = true; }
+            }
+        }
+        if (valid) {
+            obs[row] = obs_word(g, fin);
+            if (done) done[row] = fin ? 1 : 0;
+        }
+    }
+    if (valid) {
+        if (acc_dirty) aux[i].score_sum = acc;
+        if (consumed) { aux[i].n01.x = 0; nstale[i] = 1; }
+        if (renewed) { aux[i].episode = cur_ep; gkey[i] = key; }
+        if (touched || renewed) store_game(g, s01, s23, i, seats_dirty);
+    }
+}
+
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
 __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 offset, u32 episode, int mix,
                                                      int16_t *__restrict__ scores_out, int16_t *__restrict__ nsteps_out,
@@ -691,9 +800,27 @@ int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, ui
     return TAROK_OK;
 }
 
-static inline void launch_one(tarok_env *e, int fused, uint8_t *action, int16_t *reward, uint8_t *done,
+static inline void launch_krog(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward,
+                               uint8_t *done, uint16_t *trick, uint64_t *obs, int flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_krog, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards,
+                       stride, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale, e->gkey);
+}
+
+int tarok_krog_random(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,
+                      uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream) {
+    if (!e || !obs_out || cards < 1 || cards > 48 || stride < e->n) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    launch_krog(e, cards, stride, action_out, reward_out, done_out, trick_out, obs_out, flags, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+// cards: 0 = tarok_policy_random + tarok_step, 1 = tarok_step_random, >= 2 = tarok_krog_random
+static inline void launch_one(tarok_env *e, int cards, uint8_t *action, int16_t *reward, uint8_t *done,
                               uint64_t *obs, int flags, hipStream_t s) {
-    if (fused) {
+    if (cards >= 2) {
+        launch_krog(e, cards, e->n, action, reward, done, nullptr, obs, flags, s);
+    } else if (cards == 1) {
         launch_step(e, true, nullptr, nullptr, reward, done, obs, flags, s);
     } else {
         hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, (const u64 *)obs, e->gkey, action);
@@ -701,32 +828,36 @@ static inline void launch_one(tarok_env *e, int fused, uint8_t *action, int16_t 
     }
 }
 
-int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, int prefetch_every, uint8_t *action,
-                     int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
+int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int graph_chunk, int prefetch_every,
+                     uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
     if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 4096 || prefetch_every < 0) return TAROK_EINVAL;
+    if (cards_per_launch < 0 || cards_per_launch > 48) return TAROK_EINVAL;
+    int unit = cards_per_launch >= 2 ? cards_per_launch : 1;          // lock-steps per launch
+    if (n_steps % unit != 0 || graph_chunk % unit != 0) return TAROK_EINVAL;
+    if (prefetch_every % unit != 0) return TAROK_EINVAL;
     if (graph_chunk > 0 && prefetch_every > 0 && graph_chunk % prefetch_every != 0) return TAROK_EINVAL;
     if (!(flags & TAROK_AUTO_RESET)) prefetch_every = 0;
-    if (!fused && !action) return TAROK_EINVAL;
+    if (cards_per_launch == 0 && !action) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     int64_t left = n_steps;
     if (graph_chunk > 0 && left >= graph_chunk) {
-        bool hit = e->gexec && e->g_fused == fused && e->g_chunk == graph_chunk && e->g_flags == flags &&
+        bool hit = e->gexec && e->g_fused == cards_per_launch && e->g_chunk == graph_chunk && e->g_flags == flags &&
                    e->g_prefetch == prefetch_every &&
                    e->g_action == action && e->g_reward == reward_out && e->g_done == done_out && e->g_obs == obs_out;
         if (!hit) {
             if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
-            for (int k = 0; k < graph_chunk; k++) {
-                launch_one(e, fused, action, reward_out, done_out, obs_out, flags, e->cap_stream);
-                if (prefetch_every && (k + 1) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
+            for (int k = 0; k < graph_chunk; k += unit) {
+                launch_one(e, cards_per_launch, action, reward_out, done_out, obs_out, flags, e->cap_stream);
+                if (prefetch_every && (k + unit) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
             }
             HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
             hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
-            e->g_fused = fused; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
+            e->g_fused = cards_per_launch; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
             e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
         }
         while (left >= graph_chunk) {
@@ -734,9 +865,9 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int fused, int graph_chunk, 
             left -= graph_chunk;
         }
     }
-    for (int64_t k = 0; left > 0; left--, k++) {
-        launch_one(e, fused, action, reward_out, done_out, obs_out, flags, s);
-        if (prefetch_every && (k + 1) % prefetch_every == 0) launch_prefetch(e, s);
+    for (int64_t k = 0; left > 0; left -= unit, k += unit) {
+        launch_one(e, cards_per_launch, action, reward_out, done_out, obs_out, flags, s);
+        if (prefetch_every && (k + unit) % prefetch_every == 0) launch_prefetch(e, s);
     }
     HIPCHK(hipGetLastError());
     return TAROK_OK;

@@ -189,13 +189,47 @@ class TarokVecEnv:
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_prefetch(self._h, self._stream()))
 
-    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=8):
-        """n_steps lock-steps of the random policy launched from C (optionally graph-replayed)."""
+    def _krog_bufs(self, cards):
+        if getattr(self, "_kb_cards", 0) != cards:
+            with torch.cuda.device(self.device):
+                self._kb = dict(action=torch.full((cards, self.n), 255, dtype=torch.uint8, device=self.device),
+                                reward=torch.zeros((cards, self.n, 4), dtype=torch.int16, device=self.device),
+                                done=torch.zeros((cards, self.n), dtype=torch.uint8, device=self.device),
+                                trick=torch.zeros((cards, self.n), dtype=torch.int16, device=self.device),
+                                obs=torch.zeros((cards, self.n), dtype=torch.int64, device=self.device))
+            self._kb_cards = cards
+        return self._kb
+
+    def krog_random(self, cards=4, auto_reset=False):
+        """`cards` cards of every game in one launch, Bot policy in-kernel (cards=4: one trick =
+        one pass of the reference's krog).  Returns dict of [cards,N] tensors: action, reward
+        [cards,N,4] (valid where done), done, trick, obs (observation words); also updates
+        self.obs_words to the last row."""
+        kb = self._krog_bufs(cards)
         with torch.cuda.device(self.device):
-            _native.check(self.L.tarok_run_random(self._h, int(n_steps), 1 if fused else 0, int(graph_chunk),
-                                                  int(prefetch_every), self._p(self.action), self._p(self.reward), self._p(self.done),
-                                                  self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
-                                                  self._stream()))
+            _native.check(self.L.tarok_krog_random(self._h, int(cards), self.n, self._p(kb["action"]), self._p(kb["reward"]),
+                                                   self._p(kb["done"]), self._p(kb["trick"]), self._p(kb["obs"]),
+                                                   K.AUTO_RESET if auto_reset else 0, self._stream()))
+            self.obs_words.copy_(kb["obs"][cards - 1])
+        return kb
+
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=8, cards_per_launch=None):
+        """n_steps lock-steps of the random policy launched from C (optionally graph-replayed).
+        cards_per_launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = that many
+        cards per launch (tarok_krog_random); default from `fused`."""
+        cards = (1 if fused else 0) if cards_per_launch is None else int(cards_per_launch)
+        with torch.cuda.device(self.device):
+            if cards >= 2:
+                kb = self._krog_bufs(cards)
+                _native.check(self.L.tarok_run_random(self._h, int(n_steps), cards, int(graph_chunk), int(prefetch_every),
+                                                      self._p(kb["action"]), self._p(kb["reward"]), self._p(kb["done"]),
+                                                      self._p(kb["obs"]), K.AUTO_RESET if auto_reset else 0, self._stream()))
+                self.obs_words.copy_(kb["obs"][cards - 1])
+            else:
+                _native.check(self.L.tarok_run_random(self._h, int(n_steps), cards, int(graph_chunk), int(prefetch_every),
+                                                      self._p(self.action), self._p(self.reward), self._p(self.done),
+                                                      self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
+                                                      self._stream()))
 
     def rollout_random(self, episode=0, trace=False):
         """Whole random-policy games in one launch.  Returns dict of device tensors:

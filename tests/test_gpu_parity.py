@@ -263,16 +263,46 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
     # prefetch 4: every finished game is a 32-byte swap from the prefetched buffer;
     # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
-    for fused, chunk, pf in [(False, 48, 4), (True, 0, 0), (True, 64, 16), (False, 0, 2)]:
+    # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
+    for cards, chunk, pf in [(0, 48, 4), (1, 0, 0), (1, 64, 16), (0, 0, 2),
+                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0)]:
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
-        env.run_random(steps, fused=fused, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
+        env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
         ep, ss = env.counters()
-        assert (ep == ref["episode"]).all(), (fused, chunk, pf)
-        assert (ss == ref["score_sum"]).all(), (fused, chunk, pf)
-        assert (env.state() == ref["lanes"]).all(), (fused, chunk, pf)
-        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), (fused, chunk, pf)
+        cfg = (cards, chunk, pf)
+        assert (ep == ref["episode"]).all(), cfg
+        assert (ss == ref["score_sum"]).all(), cfg
+        assert (env.state() == ref["lanes"]).all(), cfg
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), cfg
         env.close()
+
+
+def test_krog_kernel_writes_what_four_single_steps_write(T, S):
+    """tarok_krog_random(cards): row c of every output equals what the c-th tarok_step_random
+    call writes (actions, observation words, done, per-trick info, scores), with and without
+    auto-reset, from aligned and mid-trick starts."""
+    n = 16384
+    for auto, cards, lead_in in [(True, 4, 0), (True, 4, 2), (False, 4, 0), (True, 8, 1), (True, 5, 0)]:
+        a = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
+        b = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
+        a.reset(); b.reset()
+        for t in range(lead_in):
+            a.step_random(auto_reset=auto); b.step_random(auto_reset=auto)
+        for rounds in range(14):
+            kb = a.krog_random(cards, auto_reset=auto)
+            for c in range(cards):
+                ob, rw, dn = b.step_random(auto_reset=auto, tricks=True)
+                assert (kb["action"][c] == b.action).all().item(), (auto, cards, rounds, c)
+                assert (kb["obs"][c] == ob.words).all().item(), (auto, cards, rounds, c)
+                assert (kb["done"][c] == dn).all().item()
+                assert (kb["trick"][c] == b.trick).all().item()
+                d = dn.bool()
+                assert (kb["reward"][c][d] == rw[d]).all().item()
+        assert (a.state() == b.state()).all()
+        ea, sa = a.counters(); eb, sb = b.counters()
+        assert (ea == eb).all() and (sa == sb).all()
+        a.close(); b.close()
 
 
 def test_auto_reset_revives_games_finished_earlier(T, O, S):
