@@ -112,8 +112,9 @@ def main():
 
     def run(steps, mode):
         """mode: 0 = policy kernel + step kernel, 1 = one card per launch, >= 2 = that many cards per launch"""
+        # the trick-per-launch kernel refills consumed next-game buffers itself: no tarok_prefetch launches
         env.run_random(steps // max(1, mode) * max(1, mode), cards_per_launch=mode, graph_chunk=chunk, auto_reset=True,
-                       prefetch_every=pf)
+                       prefetch_every=0 if mode >= 2 else pf)
 
     def timed(steps, mode):
         sharding.barrier()
@@ -160,8 +161,8 @@ def main():
                                "auto-reset (every slot live in every step)" % n,
                    "games_per_gpu": n,
                    "mode": "tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's "
-                           "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps, "
-                           "tarok_prefetch every %d steps" % (cards, chunk, pf),
+                           "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps; "
+                           "finished games' successors are dealt inside the same launch" % (cards, chunk),
                    "cards_per_launch": cards,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),

@@ -133,6 +133,16 @@ __device__ __forceinline__ u64 legal_now(const Game &g) {
     return legal_mask(hand_of(g, seat), g.nt != 0, g.trick & 63, klop_family(g.contract));
 }
 
+// observation word (tarok_env.h TAROK_OBS_*) from an already computed legal mask
+__device__ __forceinline__ u64 obs_word_with(const Game &g, bool finished_now, u64 legal) {
+    u64 o = legal;
+    o |= (u64)((g.leader + g.nt) & 3) << 54;
+    o |= (u64)(g.trick_no * 4 + g.nt) << 56;
+    if (finished_now || g.phase == TK_PHASE_DONE) o |= 1ULL << 62;
+    o |= (u64)g.error << 63;
+    return o;
+}
+
 // observation word (tarok_env.h TAROK_OBS_*)
 __device__ __forceinline__ u64 obs_word(const Game &g, bool finished_now) {
     bool play = g.phase == TK_PHASE_PLAY;
@@ -187,11 +197,16 @@ __device__ __forceinline__ u64 score_game(const Game &g) {
 // (Klop.py:27-45, Berac.py:26-44, Navadna_igra.py:72-113).
 // Returns 0 = played, 1 = played and the game is finished (scores set),
 // -1 = not a legal card: nothing changes except the error bit.
+// TRUSTED: `a` was drawn from the legal mask by the in-kernel policy, the membership test
+// (Klop.py:57-60, Navadna_igra.py:125-126) cannot fail and is skipped.
+template <bool TRUSTED = false>
 __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info) {
-    u64 legal = legal_now(g);
-    bool ok = a < 54 && ((legal >> (a & 63)) & 1);
-    g.error = ok ? g.error : 1u;     // (select, not a conditional store: keeps the struct in registers)
-    if (!ok) return -1;
+    if (!TRUSTED) {
+        u64 legal = legal_now(g);
+        bool ok = a < 54 && ((legal >> (a & 63)) & 1);
+        g.error = ok ? g.error : 1u; // (select, not a conditional store: keeps the struct in registers)
+        if (!ok) return -1;
+    }
     g.C |= 1ULL << a;
     g.trick |= a << (6 * g.nt);
     g.nt++;

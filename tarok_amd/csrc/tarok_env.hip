@@ -254,7 +254,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
     u64 scores = 0;
     u32 trick_info = 0;
     int res = -2;
-    if (play) res = apply_step(g, a, scores, trick_info);
+    if (play) res = RANDOM ? apply_step<true>(g, a, scores, trick_info) : apply_step<false>(g, a, scores, trick_info);
     bool fin = res == 1;
     if (trick && valid) trick[i] = (uint16_t)trick_info;
     if (fin) {
@@ -327,14 +327,26 @@ __global__ __launch_bounds__(TK_BLOCK) void k_step(
 // written for EVERY card: row c of action/obs/done/trick/reward (rows are `stride` games apart)
 // belongs to the c-th card of this launch.  Per card this moves less than the one-card kernel
 // (the state traffic is shared by `cards` cards) and costs 1/cards of a launch.
-// A finished game is replaced at once: first from the prefetched buffer, after that (only
-// possible when cards > 4) by the wave-cooperative deal.
+//
+// A finished game is replaced at once from the slot's prefetched next-game buffer, and the
+// buffer is refilled before the launch ends: the ~11 % of a workgroup's slots that consumed
+// theirs are compacted through LDS and dealt on dense lanes (thread j deals list entry j), so
+// the sorting-network deal costs one pass of latency per launch instead of a separate kernel,
+// and the next launch always finds its buffers full.  (A second finish inside the same launch
+// — only possible when cards > 4 — is dealt by the wave cooperatively.)
 __global__ __launch_bounds__(TK_BLOCK) void k_krog(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride,
     uint8_t *__restrict__ action_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
     uint16_t *__restrict__ trick, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
+    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u64 *__restrict__ stamps) {
+    u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
+    if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
+    __shared__ unsigned short refill_slot[TK_BLOCK];
+    __shared__ u32 refill_ep[TK_BLOCK];
+    __shared__ u32 refill_count;
+    if (threadIdx.x == 0) refill_count = 0;
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
     int64_t ic = valid ? i : n - 1;
@@ -357,18 +369,21 @@ __global__ __launch_bounds__(TK_BLOCK) void k_krog(
     }
     bool have_next = (na.x >> 62) != 0;
     bool consumed = false, renewed = false, acc_dirty = false, seats_dirty = false, touched = false;
-    for (int c = 0; c < cards; c++) {
+    // the legal mask written into the observation after card c is the one the policy needs for
+    // card c+1: computed once per card, carried in a register
+    u64 legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+    int64_t row = i;
+    for (int c = 0; c < cards; c++, row += stride) {
         bool play = valid && g.phase == TK_PHASE_PLAY;
         u32 a = 255;
-        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
+        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal);
         u64 scores = 0;
         u32 trick_info = 0;
         int res = -2;
-        if (play) res = apply_step(g, a, scores, trick_info);
+        if (play) res = apply_step<true>(g, a, scores, trick_info);
         bool fin = res == 1;
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
-        int64_t row = (int64_t)c * stride + i;
         if (valid) {
             if (action_out) action_out[row] = (uint8_t)a;
             if (trick) trick[row] = (uint16_t)trick_info;
@@ -410,21 +425,52 @@ __global__ __launch_bounds__(TK_BLOCK) void k_krog(
                         setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
                         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
                         key = dkey;
+                        consumed = true;          // its buffer is empty as well: refill below
                     }
                 }
                 if (renew) { cur_ep++; renewed = true; seats_dirty = true; }
             }
         }
+        legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
         if (valid) {
-            obs[row] = obs_word(g, fin);
+            obs[row] = obs_word_with(g, fin, legal);
             if (done) done[row] = fin ? 1 : 0;
         }
     }
     if (valid) {
         if (acc_dirty) aux[i].score_sum = acc;
-        if (consumed) { aux[i].n01.x = 0; nstale[i] = 1; }
         if (renewed) { aux[i].episode = cur_ep; gkey[i] = key; }
         if (touched || renewed) store_game(g, s01, s23, i, seats_dirty);
+    }
+    if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
+    // refill the consumed (or missing) next-game buffers of this workgroup on dense lanes
+    if (consumed) {
+        u32 pos = atomicAdd(&refill_count, 1u);
+        refill_slot[pos] = (unsigned short)threadIdx.x;
+        refill_ep[pos] = cur_ep;
+    }
+    __syncthreads();
+    if (threadIdx.x < refill_count) {
+        int64_t j = (int64_t)blockIdx.x * TK_BLOCK + refill_slot[threadIdx.x];
+        u64 k2 = game_key(seed, offset + (u64)j, (u64)refill_ep[threadIdx.x] + 1);
+        u64 h0, h1, h2, h3, tal;
+        deal_thread(k2, h0, h1, h2, h3, tal);
+        u32 cc, d, k;
+        sample_setup(k2, mix, cc, d, k);
+        Game ng;
+        setup_game(ng, h0, h1, h2, h3, tal, cc, d, k);
+        if (ng.phase == TK_PHASE_EXCHANGE) bot_exchange(ng, k2);
+        ulonglong2 pa, pb;
+        pack(ng, pa.x, pa.y, pb.x, pb.y);
+        aux[j].n23 = pb;
+        aux[j].nkey = k2;
+        aux[j].n01 = pa;
+    }
+    if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics only
+        u64 w = ((u64)blockIdx.x * TK_BLOCK + threadIdx.x) >> 6;
+        stamps[3 * w + 0] = t_real0;
+        stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
     }
 }
 
@@ -455,7 +501,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
             seat = (int)((g.leader + g.nt) & 3);
             a = policy_action(key, (u32)t, m);
             u32 ti;
-            apply_step(g, a, scores, ti);
+            apply_step<true>(g, a, scores, ti);
             played++;
         }
         if (seats) seats[(int64_t)t * n + i] = (int8_t)seat;
@@ -803,7 +849,7 @@ int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, ui
 static inline void launch_krog(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward,
                                uint8_t *done, uint16_t *trick, uint64_t *obs, int flags, hipStream_t s) {
     hipLaunchKernelGGL(k_krog, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards,
-                       stride, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale, e->gkey);
+                       stride, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale, e->gkey, e->stamps);
 }
 
 int tarok_krog_random(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,

@@ -265,7 +265,7 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
     for cards, chunk, pf in [(0, 48, 4), (1, 0, 0), (1, 64, 16), (0, 0, 2),
-                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0)]:
+                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0), (8, 64, 0), (12, 48, 0)]:
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)

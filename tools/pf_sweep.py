@@ -19,11 +19,9 @@ for fused in (True, False):
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / 4800 * 1e6)
         out["fused=%d pf=%d" % (fused, pf)] = round(best, 3)
-for cards, pf in [(2, 8), (4, 4), (4, 8), (4, 12), (4, 16), (8, 8), (8, 16), (12, 12), (16, 16), (24, 24), (48, 48)]:
+for cards, pf in [(2, 0), (4, 0), (4, 8), (8, 0), (12, 0), (16, 0), (24, 0), (48, 0)]:
     best = 1e9
-    chunk = 192 if 192 % pf == 0 and 192 % cards == 0 else 48 * max(1, pf // 48) * 1
-    if chunk % pf or chunk % cards:
-        chunk = pf * cards
+    chunk = 192 if 192 % cards == 0 else 48 * cards
     for rep in range(3):
         env.reset()
         env.run_random(960 // chunk * chunk, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
