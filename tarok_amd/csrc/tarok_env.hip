@@ -4,8 +4,16 @@
 // 4 packed uint64 lanes of tarok_device.h, stored as two 16-byte SoA arrays
 // (s01[g] = play pair {X0,X1}, s23[g] = seat pair {Y0,Y1}): every wave-level
 // load/store moves 1 KiB contiguous.  The work is integer mask algebra + popcounts bounded by
-// HBM bandwidth (no MFMA); the only cross-lane work is the wave-cooperative
-// re-deal of the few games per wave that finish in a step.
+// HBM bandwidth (no MFMA).
+//
+// Finished games are replaced at once (auto-reset) without a deal on the step's critical path:
+// every slot keeps its next TWO games ready in the buffers of its Aux record (episode e lives in
+// buffer e & 1).  A step that consumes episode k pushes "deal k+2 into buffer k & 1" onto its
+// workgroup's refill list; the NEXT launch carries extra workgroups that work those lists off
+// (sorting-network deals on dense lanes) while its own play workgroups run — the ~4 us of deal
+// latency overlaps the next trick instead of following this one.  Lists are double-buffered by
+// launch parity; a buffer is valid iff its episode tag matches, so a slot that ever finds its
+// buffer missing just deals the game itself, wave-cooperatively (ballot/readlane), same result.
 #include "tarok_device.h"
 
 #include <hip/hip_runtime.h>
@@ -15,18 +23,27 @@
 #include "../../include/tarok_env.h"
 
 #define TK_BLOCK 256
+#define TK_PF_SLOTS 1024
+#define TK_REFILL_CAP 512          // refill-list entries per play workgroup and launch (<= 2 per slot)
 
-// Per-slot side record, one 64-byte line: everything a FINISHING game touches
-// (its score sums, episode number and the prefetched next game) sits together,
-// so the sparse finish path costs one line instead of four.
-struct __attribute__((aligned(64))) Aux {
-    ulonglong2 n01, n23;   // the slot's NEXT game (play pair, seat pair), dealt ahead by k_prefetch;
-                           // phase bits of n01.x == 0: not ready
-    int4 score_sum;        // scores summed over finished games, by seat (Tarok.rezultati)
-    u64 nkey;              // RNG key of that next game
-    u32 episode;           // episode number of the slot's current game
-    u32 pad;
+// A dealt-ahead game: packed pairs, RNG key, and the episode number it is (the validity tag;
+// written last).  44 bytes.
+struct NextBuf {
+    ulonglong2 n01, n23;
+    u64 nkey;
+    u32 nep;
 };
+
+// Per-slot side record, two 64-byte lines.  Line 0 holds everything a finishing game always
+// touches (score sums, episode number) plus buffer 0; line 1 is buffer 1.
+struct __attribute__((aligned(64))) Aux {
+    ulonglong2 n01_0, n23_0; u64 nkey_0; u32 nep_0;   // buffer 0 (even episodes)
+    u32 episode;                                     // episode number of the slot's current game
+    int4 score_sum;                                  // scores summed over finished games, by seat (Tarok.rezultati)
+    ulonglong2 n01_1, n23_1; u64 nkey_1; u32 nep_1;   // buffer 1 (odd episodes)
+    u32 pad[5];
+};
+static_assert(sizeof(Aux) == 128, "Aux must be two cache lines");
 
 struct tarok_env {
     int device;
@@ -35,13 +52,17 @@ struct tarok_env {
     int mix, flags;
     ulonglong2 *s01, *s23;   // packed state
     Aux *aux;                // finish-path record per slot
-    uint8_t *nstale;         // 1 = next-game buffer empty (what k_prefetch scans); padded to 1024 slots
+    uint8_t *nstale;         // bit0 / bit1: next / next-but-one game missing and not on any refill list
+                             // (after tarok_reset; what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
-    u64 *stamps;             // diagnostics only: per-wave {realtime start, realtime end, cycles} of the last k_step
+    u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
+    u32 *rcount;             // [play workgroups][2]
+    uint32_t launch_no;      // play launches enqueued so far (parity selects the list written / worked off)
+    u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
     hipGraphExec_t gexec;
-    int g_fused, g_chunk, g_flags, g_prefetch;
+    int g_fused, g_chunk, g_flags, g_prefetch, g_par0;
     void *g_action, *g_reward, *g_done, *g_obs;
 };
 
@@ -87,8 +108,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     u64 key = game_key(seed, offset + (u64)i, episode);
     u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
     bool bad = false;
-    aux[i].n01 = make_ulonglong2(0, 0);
-    nstale[i] = 1;
+    aux[i].nep_0 = 0xFFFFFFFFu;                 // both next-game buffers: empty
+    aux[i].nep_1 = 0xFFFFFFFFu;
+    nstale[i] = 3;
     if (deals) {
         const uint8_t *p = deals + i * 54;
         u64 h[4] = {0, 0, 0, 0};
@@ -112,6 +134,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     }
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+    g.epar = episode & 1;
     if (g.phase == TK_PHASE_EXCHANGE && !(flags & TAROK_DEFER_EXCHANGE)) {
         if (choice && discards) {
             const uint8_t *q = discards + i * 3;
@@ -127,48 +150,52 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     if (flags & TAROK_CLEAR_COUNTERS) aux[i].score_sum = make_int4(0, 0, 0, 0);
 }
 
-// Deal the NEXT game (episode+1, synthetic contract, Bot exchange) of every slot
-// whose next-game buffer is empty, so that a step that finishes a game only has
-// to swap 32 bytes in.  Only a few percent of the slots are empty at a time, so
-// each workgroup first compacts the empty slots of its 1024-slot tile into an
-// LDS list (4 flags per thread, one LDS atomic per thread that found any) and
-// then deals list entry j on thread j: the sorting-network deal runs on dense
-// lanes, and waves with nothing to do leave.
-#define TK_PF_SLOTS 1024
+// Deal game `episode` of slot j ahead of time into its buffer (episode & 1).
+__device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t j, u32 episode, u64 seed, u64 offset, int mix) {
+    u64 key = game_key(seed, offset + (u64)j, (u64)episode);
+    u64 h0, h1, h2, h3, tal;
+    deal_thread(key, h0, h1, h2, h3, tal);
+    u32 c, d, k;
+    sample_setup(key, mix, c, d, k);
+    Game g;
+    setup_game(g, h0, h1, h2, h3, tal, c, d, k);
+    g.epar = episode & 1;
+    if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
+    ulonglong2 a, b;
+    pack(g, a.x, a.y, b.x, b.y);
+    if (episode & 1) { aux[j].n01_1 = a; aux[j].n23_1 = b; aux[j].nkey_1 = key; aux[j].nep_1 = episode; }
+    else             { aux[j].n01_0 = a; aux[j].n23_0 = b; aux[j].nkey_0 = key; aux[j].nep_0 = episode; }
+}
+
+// tarok_prefetch: fill, synchronously, the next-game buffers that tarok_reset emptied (flags in
+// nstale: bit0 = episode+1 missing, bit1 = episode+2 missing).  Each workgroup compacts the
+// missing buffers of its 1024-slot tile into an LDS list (4 flag bytes per thread) and deals list
+// entry j on thread j, so the sorting network runs on dense lanes.
 __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
                                                       Aux *__restrict__ aux, uint8_t *__restrict__ nstale) {
-    __shared__ unsigned short list[TK_PF_SLOTS];
+    __shared__ unsigned short list[2 * TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
     if (threadIdx.x == 0) count = 0;
     __syncthreads();
     u32 f = reinterpret_cast<const u32 *>(nstale + base)[threadIdx.x];   // 4 slots; array is padded
     if (f) {
-        u32 c = ((f & 0xFF) != 0) + ((f & 0xFF00) != 0) + ((f & 0xFF0000) != 0) + ((f >> 24) != 0);
+        u32 c = __popc(f & 0x03030303u);
         u32 pos = atomicAdd(&count, c);
 #pragma unroll
-        for (u32 k = 0; k < 4; k++)
-            if ((f >> (8 * k)) & 0xFF) list[pos++] = (unsigned short)(threadIdx.x * 4 + k);
+        for (u32 k = 0; k < 4; k++) {
+            u32 fk = (f >> (8 * k)) & 3;
+            if (fk & 1) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * 2);
+            if (fk & 2) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * 2 + 1);
+        }
+        reinterpret_cast<u32 *>(nstale + base)[threadIdx.x] = 0;
     }
     __syncthreads();
     u32 total = count;
     for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) {
-        int64_t i = base + list[j];
+        int64_t i = base + (list[j] >> 1);
         if (i >= n) continue;
-        u64 key = game_key(seed, offset + (u64)i, (u64)aux[i].episode + 1);
-        u64 h0, h1, h2, h3, tal;
-        deal_thread(key, h0, h1, h2, h3, tal);
-        u32 c, d, k;
-        sample_setup(key, mix, c, d, k);
-        Game g;
-        setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-        if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
-        ulonglong2 a, b;
-        pack(g, a.x, a.y, b.x, b.y);
-        aux[i].n23 = b;
-        aux[i].n01 = a;
-        aux[i].nkey = key;
-        nstale[i] = 0;
+        deal_into_buffer(aux, i, aux[i].episode + 1 + (list[j] & 1), seed, offset, mix);
     }
 }
 
@@ -212,180 +239,94 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
     action[i] = (uint8_t)a;
 }
 
-// One lock-step of every game (one `next(g)` per game, Tarok.py:54).
-// RANDOM: the Bot policy is evaluated in the same launch instead of reading
-// `action`.  Every lane of a wave stays alive to the end: the auto-reset tail
-// is wave-cooperative.
+// THE step kernel.  One launch plays `cards` cards of every game:
+//   RANDOM = false, cards = 1: tarok_step — the card comes from `action_in` (an external policy);
+//   RANDOM = true:  the Bot policy (Igralec.py:158-159) is evaluated in-kernel; cards = 1 is
+//                   tarok_step_random, cards = 4 one whole trick = one pass of the reference's krog
+//                   generator (Klop.py:47-79, Navadna_igra.py:115-141).
+// The packed state is read once, stays in registers while the cards are played and is written
+// once; everything a consumer of the trajectory needs is written for EVERY card: row c of
+// action/obs/done/trick/reward (rows `stride` games apart) belongs to the c-th card of the launch.
+// Per card: legal mask -> card -> apply -> (4th card of a trick) winner, Klop talon gift, Berac
+// end, end-of-game scoring, and with TAROK_AUTO_RESET the finished game's successor swapped in
+// from the slot's next-game buffer.
+//
+// Workgroups [0, play_groups) play; workgroups [play_groups, 2*play_groups) work off the refill
+// lists the PREVIOUS launch wrote (see the file header).
 template <bool RANDOM>
-__global__ __launch_bounds__(TK_BLOCK) void k_step(
-    int64_t n, u64 seed, u64 offset, int mix, int flags,
-    const uint8_t *__restrict__ action, uint8_t *__restrict__ action_out,
-    int16_t *__restrict__ reward, uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u64 *__restrict__ stamps) {
+__global__ __launch_bounds__(TK_BLOCK) void k_play(
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par,
+    const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
+    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, u64 *__restrict__ gkey,
+    u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
+    if (blockIdx.x >= play_groups) {
+        // ---- refill role: the previous launch's list of this play workgroup
+        u32 grp = blockIdx.x - play_groups;
+        u32 cnt = rcount[grp * 2 + (par ^ 1)];
+        const u64 *lst = rlist + ((int64_t)grp * 2 + (par ^ 1)) * TK_REFILL_CAP;
+        for (u32 j = threadIdx.x; j < cnt; j += TK_BLOCK) {
+            u64 en = lst[j];
+            deal_into_buffer(aux, (int64_t)grp * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
+        }
+        return;
+    }
+    // ---- play role
+    __shared__ u64 push_list[TK_REFILL_CAP];
+    __shared__ u32 push_count;
+    if (threadIdx.x == 0) push_count = 0;
+    __syncthreads();
+    u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
+    if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
-    u64 t_real0 = 0, t_cyc0 = 0;
-    if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
     int64_t ic = valid ? i : n - 1;
     Game g;
     load_game(g, s01, s23, ic);
     u64 key = 0;
-    u32 a = 255;
-    if (RANDOM) key = gkey[ic]; else a = action[ic];
-    bool play = valid && g.phase == TK_PHASE_PLAY;
+    u32 a_in = 255;
+    if (RANDOM) key = gkey[ic]; else a_in = action_in[ic];
     bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
-    // A game can only end on the 4th card of a trick, and then only in trick 12
-    // or in a Berac.  For those few lanes the loads a finish needs (score sums,
-    // episode number, the prefetched next game) are issued NOW, next to the
-    // state load, instead of as a second memory round trip after the rules.
-    bool may_end = play && g.nt == 3 && (g.trick_no == 11 || g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC);
-    bool may_renew = autoreset && valid && (may_end || g.phase == TK_PHASE_DONE);
-    int4 acc = make_int4(0, 0, 0, 0);
-    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
-    u32 cur_ep = 0;
-    u64 nkey = 0;
-    if (may_end) acc = aux[i].score_sum;
-    if (may_renew) { na = aux[i].n01; nb = aux[i].n23; nkey = aux[i].nkey; cur_ep = aux[i].episode; }
-    if (RANDOM) {
-        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal_now(g));
-        if (action_out && valid) action_out[i] = (uint8_t)a;
-    }
-    u64 scores = 0;
-    u32 trick_info = 0;
-    int res = -2;
-    if (play) res = RANDOM ? apply_step<true>(g, a, scores, trick_info) : apply_step<false>(g, a, scores, trick_info);
-    bool fin = res == 1;
-    if (trick && valid) trick[i] = (uint16_t)trick_info;
-    if (fin) {
-        if (reward) reinterpret_cast<u64 *>(reward)[i] = scores;
-        acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
-        acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
-        aux[i].score_sum = acc;
-    }
-    bool renew = false;
-    if (autoreset) {
-        // every finished game is replaced by the slot's next one: normally a 32-byte
-        // swap from the prefetched buffer; if that is empty (tarok_prefetch not called
-        // for >= 4 steps) the wave deals it cooperatively right here.
-        renew = valid && g.phase == TK_PHASE_DONE;
-        if (__ballot(renew)) {
-            u32 nep = cur_ep + 1;
-            bool swapped = false;
-            if (renew) {
-                if ((na.x >> 62) != 0) {
-                    unpack(g, na.x, na.y, nb.x, nb.y);
-                    aux[i].n01.x = 0;
-                    nstale[i] = 1;
-                    swapped = true;
-                }
-            }
-            bool deal_here = renew && !swapped;
-            u64 pend = __ballot(deal_here);
-            if (pend) {
-                if (deal_here) nkey = game_key(seed, offset + (u64)i, nep);
-                u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
-                u32 lane = __lane_id();
-                while (pend) {
-                    int l = __builtin_ctzll(pend);
-                    pend &= pend - 1;
-                    u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)nkey, l);
-                    u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(nkey >> 32), l);
-                    u64 w0, w1, w2, w3, wt;
-                    deal_wave(klo, khi, w0, w1, w2, w3, wt);
-                    if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
-                }
-                if (deal_here) {
-                    u32 c, d, k;
-                    sample_setup(nkey, mix, c, d, k);
-                    setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-                    if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, nkey);
-                }
-            }
-            if (renew) { aux[i].episode = nep; gkey[i] = nkey; }
-        }
-    }
-    if (valid) {
-        // A/B change only when a trick was resolved (n_in_trick wrapped to 0) or a new game came in
-        if (res != -2 || renew) store_game(g, s01, s23, i, renew || (res >= 0 && g.nt == 0));
-        obs[i] = obs_word(g, fin);
-        if (done) done[i] = fin ? 1 : 0;
-    }
-    if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics: never set in bench/test runs
-        u64 w = ((u64)blockIdx.x * TK_BLOCK + threadIdx.x) >> 6;
-        stamps[3 * w + 0] = t_real0;
-        stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
-        stamps[3 * w + 2] = __builtin_amdgcn_s_memtime() - t_cyc0;
-    }
-}
-
-
-// `cards` cards of every game in ONE launch with the Bot policy evaluated in-kernel; cards = 4 is
-// one whole trick = one pass of the reference's krog generator (Klop.py:47-79,
-// Navadna_igra.py:115-141).  The packed state is read once, stays in registers while the cards
-// are played, and is written once; everything a consumer of the trajectory needs is still
-// written for EVERY card: row c of action/obs/done/trick/reward (rows are `stride` games apart)
-// belongs to the c-th card of this launch.  Per card this moves less than the one-card kernel
-// (the state traffic is shared by `cards` cards) and costs 1/cards of a launch.
-//
-// A finished game is replaced at once from the slot's prefetched next-game buffer, and the
-// buffer is refilled before the launch ends: the ~11 % of a workgroup's slots that consumed
-// theirs are compacted through LDS and dealt on dense lanes (thread j deals list entry j), so
-// the sorting-network deal costs one pass of latency per launch instead of a separate kernel,
-// and the next launch always finds its buffers full.  (A second finish inside the same launch
-// — only possible when cards > 4 — is dealt by the wave cooperatively.)
-__global__ __launch_bounds__(TK_BLOCK) void k_krog(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride,
-    uint8_t *__restrict__ action_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
-    uint16_t *__restrict__ trick, u64 *__restrict__ obs,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey, u64 *__restrict__ stamps) {
-    u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
-    if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
-    __shared__ unsigned short refill_slot[TK_BLOCK];
-    __shared__ u32 refill_ep[TK_BLOCK];
-    __shared__ u32 refill_count;
-    if (threadIdx.x == 0) refill_count = 0;
-    __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
-    bool valid = i < n;
-    int64_t ic = valid ? i : n - 1;
-    Game g;
-    load_game(g, s01, s23, ic);
-    u64 key = gkey[ic];
-    bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
-    // lanes that can reach the end of their game within this launch (Berac: any trick end;
-    // the others: only in trick 12) issue their finish-path loads together with the state
+    // Lanes that can reach the end of their game within this launch (a game only ends on the 4th
+    // card of a trick: Berac on any trick, the others in trick 12) issue their finish-path loads
+    // NOW, next to the state load, instead of as a second memory round trip after the rules.
     bool berac = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-    bool spec = valid && ((g.phase == TK_PHASE_PLAY && (berac || (int)(g.trick_no * 4 + g.nt) + cards >= 48)) ||
+    bool spec = valid && ((g.phase == TK_PHASE_PLAY && (int)g.nt + cards >= 4 &&
+                           (berac || (int)(g.trick_no * 4 + g.nt) + cards >= 48)) ||
                           g.phase == TK_PHASE_DONE);
     int4 acc = make_int4(0, 0, 0, 0);
-    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
     u32 cur_ep = 0;
+    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
     u64 nkey = 0;
+    u32 nep = 0xFFFFFFFFu;
     if (spec) {
         acc = aux[i].score_sum;
-        if (autoreset) { na = aux[i].n01; nb = aux[i].n23; nkey = aux[i].nkey; cur_ep = aux[i].episode; }
+        cur_ep = aux[i].episode;
+        if (autoreset) {
+            if (g.epar) { na = aux[i].n01_0; nb = aux[i].n23_0; nkey = aux[i].nkey_0; nep = aux[i].nep_0; }   // next episode is even
+            else        { na = aux[i].n01_1; nb = aux[i].n23_1; nkey = aux[i].nkey_1; nep = aux[i].nep_1; }
+        }
     }
-    bool have_next = (na.x >> 62) != 0;
-    bool consumed = false, renewed = false, acc_dirty = false, seats_dirty = false, touched = false;
+    bool have_next = spec && autoreset && nep == cur_ep + 1;
+    u32 consumed = 0;                       // games swapped in / dealt during this launch
+    bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
-    u64 legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+    u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
     int64_t row = i;
     for (int c = 0; c < cards; c++, row += stride) {
         bool play = valid && g.phase == TK_PHASE_PLAY;
-        u32 a = 255;
-        if (play) a = policy_action(key, g.trick_no * 4 + g.nt, legal);
+        u32 a = a_in;
+        if (RANDOM) a = play ? policy_action(key, g.trick_no * 4 + g.nt, legal) : 255u;
         u64 scores = 0;
         u32 trick_info = 0;
         int res = -2;
-        if (play) res = apply_step<true>(g, a, scores, trick_info);
+        if (play) res = RANDOM ? apply_step<true>(g, a, scores, trick_info) : apply_step<false>(g, a, scores, trick_info);
         bool fin = res == 1;
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
         if (valid) {
-            if (action_out) action_out[row] = (uint8_t)a;
+            if (RANDOM && action_out) action_out[row] = (uint8_t)a;
             if (trick) trick[row] = (uint16_t)trick_info;
         }
         if (fin) {
@@ -399,11 +340,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_krog(
             if (__ballot(renew)) {
                 bool swapped = false;
                 if (renew && have_next) {
-                    unpack(g, na.x, na.y, nb.x, nb.y);
+                    unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game
                     key = nkey;
-                    have_next = false; consumed = true; swapped = true;
+                    have_next = false; swapped = true;
                 }
-                bool deal_here = renew && !swapped;
+                bool deal_here = renew && !swapped;          // buffer missing (or 2nd finish of a launch)
                 u64 pend = __ballot(deal_here);
                 if (pend) {
                     u64 dkey = 0;
@@ -423,51 +364,42 @@ __global__ __launch_bounds__(TK_BLOCK) void k_krog(
                         u32 cc, d, k;
                         sample_setup(dkey, mix, cc, d, k);
                         setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
+                        g.epar = (cur_ep + 1) & 1;
                         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
                         key = dkey;
-                        consumed = true;          // its buffer is empty as well: refill below
+                        consumed |= 2;                       // the buffers are out of step: refill both
                     }
                 }
-                if (renew) { cur_ep++; renewed = true; seats_dirty = true; }
+                if (renew) { cur_ep++; consumed += 1; seats_dirty = true; }
             }
         }
-        legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+        if (RANDOM) legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
         if (valid) {
-            obs[row] = obs_word_with(g, fin, legal);
+            obs[row] = RANDOM ? obs_word_with(g, fin, legal) : obs_word(g, fin);
             if (done) done[row] = fin ? 1 : 0;
         }
     }
     if (valid) {
         if (acc_dirty) aux[i].score_sum = acc;
-        if (renewed) { aux[i].episode = cur_ep; gkey[i] = key; }
-        if (touched || renewed) store_game(g, s01, s23, i, seats_dirty);
+        if (consumed) { aux[i].episode = cur_ep; gkey[i] = key; }
+        if (touched || consumed) store_game(g, s01, s23, i, seats_dirty);
     }
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
-    // refill the consumed (or missing) next-game buffers of this workgroup on dense lanes
+    // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 and cur+2.
+    // One swap-in leaves cur+1 valid in the other buffer: only cur+2 is new; anything else: both.
     if (consumed) {
-        u32 pos = atomicAdd(&refill_count, 1u);
-        refill_slot[pos] = (unsigned short)threadIdx.x;
-        refill_ep[pos] = cur_ep;
+        u32 np = consumed == 1 ? 1u : 2u;
+        u32 pos = atomicAdd(&push_count, np);
+        if (np == 2) push_list[pos++] = ((u64)(cur_ep + 1) << 32) | threadIdx.x;
+        push_list[pos] = ((u64)(cur_ep + 2) << 32) | threadIdx.x;
     }
     __syncthreads();
-    if (threadIdx.x < refill_count) {
-        int64_t j = (int64_t)blockIdx.x * TK_BLOCK + refill_slot[threadIdx.x];
-        u64 k2 = game_key(seed, offset + (u64)j, (u64)refill_ep[threadIdx.x] + 1);
-        u64 h0, h1, h2, h3, tal;
-        deal_thread(k2, h0, h1, h2, h3, tal);
-        u32 cc, d, k;
-        sample_setup(k2, mix, cc, d, k);
-        Game ng;
-        setup_game(ng, h0, h1, h2, h3, tal, cc, d, k);
-        if (ng.phase == TK_PHASE_EXCHANGE) bot_exchange(ng, k2);
-        ulonglong2 pa, pb;
-        pack(ng, pa.x, pa.y, pb.x, pb.y);
-        aux[j].n23 = pb;
-        aux[j].nkey = k2;
-        aux[j].n01 = pa;
-    }
+    u32 total = push_count;
+    u64 *lst = rlist + ((int64_t)blockIdx.x * 2 + par) * TK_REFILL_CAP;
+    for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) lst[j] = push_list[j];
+    if (threadIdx.x == 0) rcount[blockIdx.x * 2 + par] = total;
     if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics only
-        u64 w = ((u64)blockIdx.x * TK_BLOCK + threadIdx.x) >> 6;
+        u64 w = (u64)i >> 6;
         stamps[3 * w + 0] = t_real0;
         stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
@@ -659,7 +591,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglo
 // hand-built positions).  Cards on the table go back to whoever played them, the un-owned
 // talon to where setup_game parks it.
 __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__restrict__ in,
-                                                       ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23) {
+                                                       ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23,
+                                                       const Aux *__restrict__ aux) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 m = in[9 * n + i];
@@ -672,6 +605,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.team = (u32)(m >> 42) & 15;
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
+    g.epar = aux[i].episode & 1;
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
     u64 seatc[4];
@@ -735,6 +669,10 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     if (r == hipSuccess) r = hipMalloc((void **)&e->aux, (size_t)n_games * sizeof(Aux));
     if (r == hipSuccess) r = hipMalloc((void **)&e->nstale, stale_bytes);
     if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
+    size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
+    if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, groups * 2 * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->rcount, 0, groups * 2 * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->aux, 0, (size_t)n_games * sizeof(Aux));
@@ -756,6 +694,7 @@ void tarok_destroy(tarok_env *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
+    (void)hipFree(e->rlist); (void)hipFree(e->rcount);
     delete e;
 }
 
@@ -772,6 +711,7 @@ int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8
     if ((talon_choice == nullptr) != (discards == nullptr)) return TAROK_EINVAL;
     if (contract && !declarer) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemsetAsync(e->rcount, 0, (size_t)((e->n + TK_BLOCK - 1) / TK_BLOCK) * 2 * sizeof(u32), (hipStream_t)stream));
     hipLaunchKernelGGL(k_reset, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
                        episode, e->mix, flags, deals, contract, declarer, king_suit, talon_choice, discards, e->s01,
                        e->s23, e->aux, e->nstale, e->gkey);
@@ -806,24 +746,29 @@ int tarok_legal_actions(tarok_env *e, uint64_t *obs_out, int8_t *seat_out, void 
     return TAROK_OK;
 }
 
-static inline void launch_step(tarok_env *e, bool random, const uint8_t *action, uint8_t *action_out,
-                               int16_t *reward, uint8_t *done, uint64_t *obs, int flags, hipStream_t s,
-                               uint16_t *trick = nullptr) {
+// One play launch: play workgroups + as many refill workgroups (previous launch's lists).
+static inline void launch_play(tarok_env *e, bool random, int cards, int64_t stride, const uint8_t *action_in,
+                               uint8_t *action_out, int16_t *reward, uint8_t *done, uint16_t *trick, uint64_t *obs,
+                               int flags, hipStream_t s) {
+    u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
+    u32 par = e->launch_no & 1u;
+    e->launch_no++;
+    dim3 grid(2 * groups);
     if (random)
-        hipLaunchKernelGGL(k_step<true>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
-                           e->gkey, e->stamps);
+        hipLaunchKernelGGL(k_play<true>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
+                           groups, par, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           e->gkey, e->rlist, e->rcount, e->stamps);
     else
-        hipLaunchKernelGGL(k_step<false>, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix,
-                           flags, action, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale,
-                           e->gkey, e->stamps);
+        hipLaunchKernelGGL(k_play<false>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
+                           groups, par, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           e->gkey, e->rlist, e->rcount, e->stamps);
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
                uint64_t *obs_out, int flags, void *stream) {
     if (!e || !action || !obs_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    launch_step(e, false, action, nullptr, reward_out, done_out, obs_out, flags, (hipStream_t)stream, trick_out);
+    launch_play(e, false, 1, e->n, action, nullptr, reward_out, done_out, trick_out, obs_out, flags, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -841,22 +786,17 @@ int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, ui
                       uint64_t *obs_out, int flags, void *stream) {
     if (!e || !obs_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    launch_step(e, true, nullptr, action_out, reward_out, done_out, obs_out, flags, (hipStream_t)stream, trick_out);
+    launch_play(e, true, 1, e->n, nullptr, action_out, reward_out, done_out, trick_out, obs_out, flags, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
-}
-
-static inline void launch_krog(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward,
-                               uint8_t *done, uint16_t *trick, uint64_t *obs, int flags, hipStream_t s) {
-    hipLaunchKernelGGL(k_krog, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards,
-                       stride, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux, e->nstale, e->gkey, e->stamps);
 }
 
 int tarok_krog_random(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,
                       uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream) {
     if (!e || !obs_out || cards < 1 || cards > 48 || stride < e->n) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    launch_krog(e, cards, stride, action_out, reward_out, done_out, trick_out, obs_out, flags, (hipStream_t)stream);
+    launch_play(e, true, cards, stride, nullptr, action_out, reward_out, done_out, trick_out, obs_out, flags,
+                (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -864,13 +804,11 @@ int tarok_krog_random(tarok_env *e, int cards, int64_t stride, uint8_t *action_o
 // cards: 0 = tarok_policy_random + tarok_step, 1 = tarok_step_random, >= 2 = tarok_krog_random
 static inline void launch_one(tarok_env *e, int cards, uint8_t *action, int16_t *reward, uint8_t *done,
                               uint64_t *obs, int flags, hipStream_t s) {
-    if (cards >= 2) {
-        launch_krog(e, cards, e->n, action, reward, done, nullptr, obs, flags, s);
-    } else if (cards == 1) {
-        launch_step(e, true, nullptr, nullptr, reward, done, obs, flags, s);
+    if (cards >= 1) {
+        launch_play(e, true, cards, e->n, nullptr, cards >= 2 ? action : nullptr, reward, done, nullptr, obs, flags, s);
     } else {
         hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, (const u64 *)obs, e->gkey, action);
-        launch_step(e, false, action, nullptr, reward, done, obs, flags, s);
+        launch_play(e, false, 1, e->n, action, nullptr, reward, done, nullptr, obs, flags, s);
     }
 }
 
@@ -882,6 +820,7 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
     if (n_steps % unit != 0 || graph_chunk % unit != 0) return TAROK_EINVAL;
     if (prefetch_every % unit != 0) return TAROK_EINVAL;
     if (graph_chunk > 0 && prefetch_every > 0 && graph_chunk % prefetch_every != 0) return TAROK_EINVAL;
+    if (graph_chunk > 0 && ((graph_chunk / unit) & 1)) return TAROK_EINVAL;   // even launch count: parity survives a replay
     if (!(flags & TAROK_AUTO_RESET)) prefetch_every = 0;
     if (cards_per_launch == 0 && !action) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
@@ -894,20 +833,26 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
         if (!hit) {
             if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
             hipGraph_t graph = nullptr;
+            uint32_t saved = e->launch_no;                   // capture enqueues nothing: restore the count after it
+            e->g_par0 = (int)(saved & 1u);
             HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
             for (int k = 0; k < graph_chunk; k += unit) {
                 launch_one(e, cards_per_launch, action, reward_out, done_out, obs_out, flags, e->cap_stream);
                 if (prefetch_every && (k + unit) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
             }
             HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
+            e->launch_no = saved;
             hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
             e->g_fused = cards_per_launch; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
             e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
         }
+        if ((int)(e->launch_no & 1u) != e->g_par0)           // a launch with no cards: works the pending lists off, flips parity
+            launch_play(e, true, 0, e->n, nullptr, nullptr, nullptr, nullptr, nullptr, obs_out, flags, s);
         while (left >= graph_chunk) {
             HIPCHK(hipGraphLaunch(e->gexec, s));
+            e->launch_no += (uint32_t)(graph_chunk / unit);
             left -= graph_chunk;
         }
     }
@@ -968,7 +913,7 @@ int tarok_set_state(tarok_env *e, const uint64_t *lanes_in, void *stream) {
     if (!e || !lanes_in) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_set_state, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const u64 *)lanes_in,
-                       e->s01, e->s23);
+                       e->s01, e->s23, e->aux);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

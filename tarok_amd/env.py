@@ -213,7 +213,7 @@ class TarokVecEnv:
             self.obs_words.copy_(kb["obs"][cards - 1])
         return kb
 
-    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=8, cards_per_launch=None):
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=0, cards_per_launch=None):
         """n_steps lock-steps of the random policy launched from C (optionally graph-replayed).
         cards_per_launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = that many
         cards per launch (tarok_krog_random); default from `fused`."""
