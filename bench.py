@@ -133,7 +133,7 @@ def main():
     # `graph_chunk` steps; tarok_prefetch every `prefetch_every` steps deals the finished slots'
     # next games.
     env.reset(episode=0)
-    run(args.warmup, cards)
+    run(max(args.warmup, chunk), cards)          # at least one whole chunk: the graph is captured here, untimed
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream = torch.cuda.current_stream(dev)
     sharding.barrier()
@@ -201,13 +201,13 @@ def main():
         # ---- side measurements (not `value`)
         # (a) the two-kernel C-ABI path: tarok_policy_random writes the action array, tarok_step consumes it
         env.reset(episode=0)
-        run(args.warmup, 0)
+        run(max(args.warmup, chunk), 0)
         dta = timed(args.steps, 0)
         out["api_two_kernel"] = {"value": total_steps / dta, "unit": "env steps/s", "ms_per_step": dta / args.steps * 1e3,
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
         # (a') one card per launch with the policy in-kernel (tarok_step_random)
         env.reset(episode=0)
-        run(args.warmup, 1)
+        run(max(args.warmup, chunk), 1)
         dt1 = timed(args.steps, 1)
         out["one_card_per_launch"] = {"value": total_steps / dt1, "unit": "env steps/s", "ms_per_step": dt1 / args.steps * 1e3,
                                       "note": "tarok_step_random: 1 launch per lock-step"}
