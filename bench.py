@@ -169,11 +169,10 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_krog; k_step when cards = 1): HIP events on the
-        # launch stream around the timed region above; launch duration = region time / launches
-        # (the region also holds 1 k_prefetch per `prefetch_every` steps and every launch gap, all
-        # charged to the step kernel -> a lower bound on its bandwidth).  One launch processes
-        # n x cards steps, each 54 algorithmic bytes.
+        # ---- roofline of the dominant kernel (k_play<true>): HIP events on the launch stream around
+        # the timed region above; launch duration = region time / launches (every launch gap is
+        # charged to the kernel -> a lower bound on its bandwidth).  One launch processes n x cards
+        # steps, each 54 algorithmic bytes.
         launches = args.steps // cards
         k_us = ev_ms * 1e3 / launches
         algo_bytes = ALGO_BYTES_PER_STEP * n * cards
@@ -184,10 +183,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_65536.json")
         if n == 65536 and os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("k_krog_traffic_bytes_per_launch" if cards == 4 else
-                                           ("k_step_true_traffic_bytes_per_launch" if cards == 1 else "-"))
+                traffic = json.load(f).get("k_play_traffic_bytes_per_launch_cards%d" % cards)
             traffic_src = "profiles/r01_pmc_fetch_write_65536.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "k_krog (tarok_krog_random)" if cards > 1 else "k_step<true> (tarok_step_random)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_play<true> (%s)" % ("tarok_krog_random" if cards > 1 else "tarok_step_random"),
                            "achieved": achieved,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_src,

@@ -130,18 +130,18 @@ int tarok_legal_actions(tarok_env *env, uint64_t *obs_out, int8_t *seat_out, voi
  *              trick; then 0x8000 | Roka.vrednost_stiha(stih) << 4 | seat that took it
  *              (Roka.py:76-95; stih = the 4 cards, 5 with Klop's talon card)
  *   obs_out    [N] u64 observation for the NEXT move (see TAROK_OBS_*)
- *   flags      TAROK_AUTO_RESET: a game that finishes is re-dealt at once
- *              (episode+1, synthetic contract, Bot exchange); obs_out then
- *              describes the new game and keeps TAROK_OBS_DONE set. */
+ *   flags      TAROK_AUTO_RESET: a game that finishes is replaced at once by the slot's
+ *              next game (episode+1, synthetic contract, Bot exchange, dealt ahead of
+ *              time); obs_out then describes the new game and keeps TAROK_OBS_DONE set. */
 int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8_t *done_out,
                uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
-/* Deal, ahead of time, the next game (episode+1, synthetic contract, Bot
- * exchange) of every slot whose next-game buffer is empty.  With it a
- * TAROK_AUTO_RESET step replaces a finished game by a 32-byte swap; call it at
- * least every 4 steps (the shortest game, a lost Berac, is 4 cards).  Slots
- * whose buffer is empty when they finish are dealt inside the step kernel
- * instead (same result, slower).  tarok_reset calls it. */
+/* Fill, synchronously, every next-game buffer that tarok_reset emptied (each slot keeps its next
+ * TWO games dealt ahead: episode+1 and episode+2, synthetic contract, Bot exchange).  tarok_reset
+ * calls it; afterwards the step kernels keep the buffers full themselves — a step that swaps a
+ * finished game's successor in puts the replacement deal on a list that extra workgroups of the
+ * NEXT step launch work off while that step plays — so callers normally never need this.  A slot
+ * that finds its buffer missing anyway deals the game inside the step kernel (same result). */
 int tarok_prefetch(tarok_env *env, void *stream);
 
 /* Bot_igralec.igraj_karto (Igralec.py:158-159): uniform choice among the legal
@@ -169,8 +169,8 @@ int tarok_krog_random(tarok_env *env, int cards, int64_t stride, uint8_t *action
  * cards_per_launch = 0: tarok_policy_random + tarok_step per step;  1: tarok_step_random;
  * c >= 2: tarok_krog_random(c) — n_steps, graph_chunk and prefetch_every must be multiples of c
  * and the buffers hold c rows of N (action [c,N], reward_out [c,N,4], done_out [c,N], obs_out [c,N]).
- * prefetch_every = k > 0: tarok_prefetch after every k-th step (graph_chunk must
- * be a multiple of k); only with TAROK_AUTO_RESET.
+ * prefetch_every = k > 0: an extra tarok_prefetch after every k-th step (graph_chunk must be a
+ * multiple of k); normally 0.  graph_chunk must hold an even number of launches.
  * Buffers otherwise as in tarok_step (action [N] u8 scratch is required for cards_per_launch = 0). */
 int tarok_run_random(tarok_env *env, int64_t n_steps, int cards_per_launch, int graph_chunk,
                      int prefetch_every, uint8_t *action, int16_t *reward_out, uint8_t *done_out,

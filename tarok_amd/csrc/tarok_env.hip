@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/tarok_env.h"
@@ -59,6 +60,7 @@ struct tarok_env {
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
     u32 *rcount;             // [play workgroups][2]
     uint32_t launch_no;      // play launches enqueued so far (parity selects the list written / worked off)
+    uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -256,21 +258,22 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
 // PREVIOUS launch wrote (see the file header).
 template <bool RANDOM>
 __global__ __launch_bounds__(TK_BLOCK) void k_play(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, u64 *__restrict__ gkey,
     u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
     if (blockIdx.x >= play_groups) {
-        // ---- refill role: the lists the previous launch wrote for TK_REFILL_FAN play workgroups,
+        // ---- refill role: the lists the previous launch wrote for `fan` play workgroups,
         // concatenated so that the sorting-network deals run on dense lanes (~11 % of the slots
-        // of a group finish per trick: 8 lists fill a 256-thread workgroup)
-        u32 g0 = (blockIdx.x - play_groups) * TK_REFILL_FAN;
+        // of a group finish per trick: 8 lists fill a 256-thread workgroup).  Small batches use a
+        // smaller fan: a refill workgroup that needs a second pass would outlast the play.
+        u32 g0 = (blockIdx.x - play_groups) * fan;
         u32 cum[TK_REFILL_FAN + 1];
         cum[0] = 0;
 #pragma unroll
         for (u32 q = 0; q < TK_REFILL_FAN; q++)
-            cum[q + 1] = cum[q] + ((g0 + q < play_groups) ? rcount[(g0 + q) * 2 + (par ^ 1)] : 0u);
+            cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[(g0 + q) * 2 + (par ^ 1)] : 0u);
         for (u32 j = threadIdx.x; j < cum[TK_REFILL_FAN]; j += TK_BLOCK) {
             u32 q = 0;
 #pragma unroll
@@ -675,6 +678,9 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     tarok_env *e = new tarok_env();
     memset(e, 0, sizeof *e);
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
+    // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
+    e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
+    if (const char *f = getenv("TAROK_REFILL_FAN")) { int v = atoi(f); if (v >= 1 && v <= TK_REFILL_FAN) e->refill_fan = (uint32_t)v; }
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
@@ -765,14 +771,15 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 par = e->launch_no & 1u;
     e->launch_no++;
-    dim3 grid(groups + (groups + TK_REFILL_FAN - 1) / TK_REFILL_FAN);
+    u32 fan = e->refill_fan;
+    dim3 grid(groups + (groups + fan - 1) / fan);
     if (random)
         hipLaunchKernelGGL(k_play<true>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, par, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
                            e->gkey, e->rlist, e->rcount, e->stamps);
     else
         hipLaunchKernelGGL(k_play<false>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, par, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
                            e->gkey, e->rlist, e->rcount, e->stamps);
 }
 
