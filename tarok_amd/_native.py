@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "tarok_env.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "tarok_device.h"), os.path.join(HERE, "csrc", "deal_network.inc"),
         os.path.join(ROOT, "include", "tarok_env.h")]
-LIB_PATH = os.path.join(HERE, "libtarokenv.so")
+LIB_PATH = os.environ.get("TAROK_LIB") or os.path.join(HERE, "libtarokenv.so")   # TAROK_LIB: A/B diagnostics only
 ARCH = "gfx950"
 
 SYMBOLS = [
