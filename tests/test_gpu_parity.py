@@ -613,3 +613,34 @@ def test_four_million_games_rollout_bit_exact(T, O, S):
     assert (out["nsteps"].cpu().numpy() == ref["nsteps"]).all()
     assert (out["scores"].cpu().numpy() == ref["scores"]).all()
     env.close()
+
+
+def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S):
+    """Graph replays, eager one-card steps, tricks, the two-kernel path and a mid-run reset, mixed
+    (odd launch counts between graphs exercise the parity flush): still the oracle's games."""
+    n, seed = 20000, 41
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    env.reset()
+    steps = 0
+    env.run_random(96, cards_per_launch=4, graph_chunk=48, auto_reset=True); steps += 96
+    for _ in range(3):
+        env.step_random(auto_reset=True); steps += 1
+    env.run_random(96, cards_per_launch=4, graph_chunk=48, auto_reset=True); steps += 96      # parity flipped: flush
+    obs = env.legal_actions()
+    for _ in range(5):
+        obs, _, _ = env.step(env.policy_random(obs), auto_reset=True); steps += 1
+    env.krog_random(7, auto_reset=True); steps += 7
+    env.run_random(64, cards_per_launch=1, graph_chunk=32, auto_reset=True); steps += 64
+    env.run_random(60, cards_per_launch=0, graph_chunk=20, auto_reset=True); steps += 60
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
+    ep, ss = env.counters()
+    assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
+    assert (env.state() == ref["lanes"]).all()
+    # a reset in the middle of everything starts clean (lists dropped, buffers refilled)
+    env.reset(episode=5)
+    env.run_random(192, cards_per_launch=4, graph_chunk=48, auto_reset=True)
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, 192, episode0=5)
+    ep, ss = env.counters()
+    assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
+    assert (env.state() == ref["lanes"]).all()
+    env.close()
