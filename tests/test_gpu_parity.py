@@ -644,3 +644,21 @@ def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S):
     assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
     assert (env.state() == ref["lanes"]).all()
     env.close()
+
+
+def test_config1_single_klop_game_through_the_main_equivalent(T, O, S):
+    """BASELINE config 1: ONE 4-player Klop game (the reference supports 4 players only,
+    SURVEY §0) driven through the build's main-equivalent with reference-shaped players;
+    scores equal the oracle's for the same deal and cards."""
+    from tarok_amd import main as M
+    seed = 6
+    shared = {}
+    players = [_SpecPlayer(i, S, seed, S.MIX_FIXED + S.KLOP, shared) for i in range(4)]
+    out = M.main(st_iger=1, iterations=1, seed=seed, igralci=players, verbose=False)
+    ref = O.rollout(seed, 0, 1, 0, S.MIX_FIXED + S.KLOP)
+    order = {p.ime: p.seat[0] for p in players}                  # seats after main's shuffle
+    assert [out[0][str(i)] for i in range(4)] == [int(ref["scores"][0][order[str(i)]]) for i in range(4)]
+    assert shared["tricks"][0] == [5] * 6 + [4] * 6
+    # and the Bot players of the reference run through it too
+    res = M.main(st_iger=32, iterations=2, seed=1, verbose=False)
+    assert len(res) == 2 and all(len(r) == 4 for r in res)
