@@ -28,16 +28,10 @@
 #define TK_REFILL_CAP 512          // refill-list entries per play workgroup and launch (<= 2 per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 
-// A dealt-ahead game: packed pairs, RNG key, and the episode number it is (the validity tag;
-// written last).  44 bytes.
-struct NextBuf {
-    ulonglong2 n01, n23;
-    u64 nkey;
-    u32 nep;
-};
-
-// Per-slot side record, two 64-byte lines.  Line 0 holds everything a finishing game always
-// touches (score sums, episode number) plus buffer 0; line 1 is buffer 1.
+// Per-slot side record, two 64-byte lines.  A next-game buffer = the dealt-ahead game's packed
+// pairs, its RNG key and the episode number it is (the validity tag, written last).  Line 0
+// holds everything a finishing game always touches (score sums, episode number) plus buffer 0;
+// line 1 is buffer 1.
 struct __attribute__((aligned(64))) Aux {
     ulonglong2 n01_0, n23_0; u64 nkey_0; u32 nep_0;   // buffer 0 (even episodes)
     u32 episode;                                     // episode number of the slot's current game
