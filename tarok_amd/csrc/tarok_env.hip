@@ -131,7 +131,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     }
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 1;
+    g.epar = episode & 1; g.pend = 0;
     if (g.phase == TK_PHASE_EXCHANGE && !(flags & TAROK_DEFER_EXCHANGE)) {
         if (choice && discards) {
             const uint8_t *q = discards + i * 3;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
     sample_setup(key, mix, c, d, k);
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 1;
+    g.epar = episode & 1; g.pend = 0;
     if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
     ulonglong2 a, b;
     pack(g, a.x, a.y, b.x, b.y);
@@ -316,7 +316,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
             else        { na = aux[i].n01_1; nb = aux[i].n23_1; nkey = aux[i].nkey_1; nep = aux[i].nep_1; }
         }
     }
-    bool have_next = spec && autoreset && nep == cur_ep + 1;
+    // (pend: the buffer was put on a refill list by the previous launch together with its
+    //  sibling, i.e. it is being written right now by a refill workgroup: do not look at it)
+    bool was_pend = valid && g.pend != 0;
+    bool have_next = spec && autoreset && !was_pend && nep == cur_ep + 1;
+    g.pend = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
     bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
                         u32 cc, d, k;
                         sample_setup(dkey, mix, cc, d, k);
                         setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
-                        g.epar = (cur_ep + 1) & 1;
+                        g.epar = (cur_ep + 1) & 1; g.pend = 0;
                         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
                         key = dkey;
                         consumed |= 2;                       // the buffers are out of step: refill both
@@ -389,9 +393,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
         }
     }
     if (valid) {
+        if (consumed > 1) g.pend = 1;        // both buffers go on the list: the next launch must not read them
         if (acc_dirty) aux[i].score_sum = acc;
         if (consumed) { aux[i].episode = cur_ep; gkey[i] = key; }
-        if (touched || consumed) store_game(g, s01, s23, i, seats_dirty);
+        if (touched || consumed || was_pend) store_game(g, s01, s23, i, seats_dirty || was_pend);
     }
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 and cur+2.
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.team = (u32)(m >> 42) & 15;
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
-    g.epar = aux[i].episode & 1;
+    g.epar = aux[i].episode & 1; g.pend = 0;
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
     u64 seatc[4];
