@@ -203,6 +203,20 @@ int tarok_observe(tarok_env *env, void *features_out, void *stream);
 int tarok_sample_policy(tarok_env *env, const void *logits_bf16, const uint64_t *obs,
                         uint8_t *action_out, float *logp_out, void *stream);
 
+/* A whole learned-policy step in one launch: observation features (as tarok_observe) -> MLP
+ * 256 -> 256 -> 256 -> 64 with ReLU (bf16 MFMA, f32 accumulate; outputs 0..53 = card logits,
+ * output 54 = state value) -> masked categorical sample (as tarok_sample_policy).
+ *   w1, w2 (256 outputs), w3 (64 outputs), bf16, 256 inputs each, in MFMA fragment order: the
+ *   16-byte element ((o / 32) * 16 + k / 16) * 64 + ((k / 8) % 2) * 32 + o % 32 holds
+ *   W[o][8 * (k / 8) .. + 7] of the [out][in] matrix (torch.nn.Linear.weight), i.e.
+ *   W.view(out/32, 32, 16, 2, 8).permute(0, 2, 3, 1, 4) — a wave's weight load is then contiguous;
+ *   b1, b2 [256] f32, b3 [64] f32;  obs [N] observation words;
+ *   action_out [N] u8, logp_out [N] f32 (may be NULL), value_out [N] f32 (may be NULL),
+ *   features_out [N,256] bf16 (may be NULL): the features, for the learner's update. */
+int tarok_policy_mlp(tarok_env *env, const void *w1, const float *b1, const void *w2, const float *b2,
+                     const void *w3, const float *b3, const uint64_t *obs, uint8_t *action_out,
+                     float *logp_out, float *value_out, void *features_out, void *stream);
+
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */
 int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);

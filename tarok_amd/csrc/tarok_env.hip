@@ -563,6 +563,170 @@ __global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__r
     if (logp) logp[i] = __logf(pe / sum);
 }
 
+
+// ---------------------------------------------------------------------------
+// Fused policy step for a learner: observation features -> MLP 256-256-256-64
+// (bf16 MFMA, f32 accumulate) -> masked categorical sample, in ONE launch.  The features never
+// leave the chip (built in LDS from the 32-byte packed state), the activations go LDS -> MFMA ->
+// LDS, only action / log-prob / value (+ optionally the features, for the learner's update) are
+// written.  Replaces tarok_observe + 4 framework GEMMs + bias/ReLU kernels + tarok_sample_policy
+// (~150 MB of activation traffic per 65,536 games) — the one place in this build where work is
+// GEMM shaped, so the one place that uses the matrix cores.
+//
+// Workgroup = 256 threads = 4 waves, 64 games.  v_mfma_f32_32x32x16_bf16: lane l (r = l & 31,
+// h = l >> 5) holds A[row r][k = 8h..8h+7] and B[k = 8h..8h+7][col r]; D: col = l & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 h.  A = activations [game][feature] from LDS (row stride
+// 264 bf16 = 528 B: the 16 lanes of a ds_read_b128 group hit 16 different 4-bank slots),
+// B[k][n] = W[n][k] read straight from the row-major [out][in] weight (16 contiguous bytes per
+// lane, L2 resident).  Layers 1-2: wave w owns output columns [64w, 64w+64) x all 64 games
+// (2x2 tiles, 64 MFMAs); layer 3 (64 outputs = 54 card logits, value in column 54): one 32x32
+// tile per wave.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define PM_M 64
+#define PM_LD 264
+
+__device__ __forceinline__ void mlp_layer256(const __bf16 *__restrict__ xin, __bf16 *__restrict__ xout,
+                                             const __bf16 *__restrict__ w, const float *__restrict__ bias) {
+    u32 lane = __lane_id(), wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    u32 n0 = wave * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[mt][nt][j] = 0.f;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; kk++) {
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) a[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 16 * kk + 8 * h);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) b[nt] = reinterpret_cast<const bf16x8 *>(w)[((wave * 2 + nt) * 16 + kk) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        u32 ncol = n0 + 32 * nt + r;
+        float bv = bias[ncol];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                u32 m = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * h;
+                xout[m * PM_LD + ncol] = (__bf16)fmaxf(acc[mt][nt][j] + bv, 0.f);
+            }
+    }
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
+    int64_t n, const ulonglong2 *__restrict__ s01, const ulonglong2 *__restrict__ s23, const u64 *__restrict__ obs,
+    const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
+    const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
+    const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
+    uint4 *__restrict__ features_out) {
+    __shared__ __attribute__((aligned(16))) __bf16 X0[PM_M * PM_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 X1[PM_M * PM_LD];
+    __shared__ u64 ext[PM_M][4];
+    int64_t base = (int64_t)blockIdx.x * PM_M;
+    u32 tid = threadIdx.x;
+    // ---- the four 64-bit feature words of each game (same definition as k_observe)
+    if (tid < PM_M) {
+        int64_t i = base + tid < n ? base + tid : n - 1;
+        Game g;
+        load_game(g, s01, s23, i);
+        u32 seat = (g.leader + g.nt) & 3;
+        bool live = g.phase == TK_PHASE_PLAY;
+        u64 on_table = 0;
+        for (u32 j = 0; j < g.nt; j++) on_table |= 1ULL << ((g.trick >> (6 * j)) & 63);
+        u64 f1 = (u64)(1u << ((g.declarer - seat) & 3)) | ((u64)(1u << g.nt) << 4) | ((u64)((g.team >> seat) & 1) << 8) |
+                 ((u64)(has_king(g.contract) ? 1u : 0u) << 9);
+        u64 f2 = (has_king(g.contract) ? (u64)(1u << g.king) : 0) | ((u64)g.trick_no << 4);
+        ext[tid][0] = hand_of(g, seat) | ((u64)(1u << g.contract) << 54);
+        ext[tid][1] = (live ? legal_now(g) : 0) | (f1 << 54);
+        ext[tid][2] = on_table | (f2 << 54);
+        ext[tid][3] = (g.C & ~talon_unowned(g) & ~on_table) | ((u64)(live ? 1u : 0u) << 54);
+    }
+    __syncthreads();
+    {   // expand to bf16 0.0 / 1.0: thread = (game, 64-feature region), 8 x 16-byte LDS stores
+        u32 gme = tid >> 2, q = tid & 3;
+        u64 wd = ext[gme][q];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            u32 byte = (u32)(wd >> (8 * c)) & 255u;
+            uint4 v;
+            v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
+            v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
+            v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
+            v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+            *reinterpret_cast<uint4 *>(X0 + gme * PM_LD + 64 * q + 8 * c) = v;
+            if (features_out && base + gme < n) features_out[(base + gme) * 32 + q * 8 + c] = v;
+        }
+    }
+    __syncthreads();
+    mlp_layer256(X0, X1, w1, b1);
+    __syncthreads();
+    mlp_layer256(X1, X0, w2, b2);
+    __syncthreads();
+    // ---- layer 3: 64 outputs, one 32x32 tile per wave; f32 results to LDS [64][65]
+    float *L = reinterpret_cast<float *>(X1);
+    {
+        u32 lane = __lane_id(), wave = tid >> 6, r = lane & 31, h = lane >> 5;
+        u32 mt = wave >> 1, nt = wave & 1;
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] = 0.f;
+#pragma unroll 4
+        for (int kk = 0; kk < 16; kk++) {
+            bf16x8 a = *reinterpret_cast<const bf16x8 *>(X0 + (32 * mt + r) * PM_LD + 16 * kk + 8 * h);
+            bf16x8 b = reinterpret_cast<const bf16x8 *>(w3)[(nt * 16 + kk) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+        u32 ncol = 32 * nt + r;
+        float bv = b3[ncol];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            u32 m = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * h;
+            L[m * 65 + ncol] = acc[j] + bv;
+        }
+    }
+    __syncthreads();
+    // ---- masked categorical sample, one lane per game (same draw as k_sample)
+    if (tid < PM_M && base + tid < n) {
+        int64_t i = base + tid;
+        const float *row = L + tid * 65;
+        if (value) value[i] = row[54];
+        u64 o = obs[i];
+        u64 m = o & TAROK_OBS_MASK;
+        if (!m) { action[i] = 255; if (logp) logp[i] = 0.f; return; }
+        float mx = -3.0e38f;
+        for (int c = 0; c < 54; c++) mx = ((m >> c) & 1) ? fmaxf(mx, row[c]) : mx;
+        float sum = 0.f;
+        for (int c = 0; c < 54; c++) sum += ((m >> c) & 1) ? __expf(row[c] - mx) : 0.f;
+        u32 rr = rng32(gkey[i], 192u + ((u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u));
+        float u = ((float)(rr >> 8) + 0.5f) * (1.0f / 16777216.0f) * sum;
+        float acc = 0.f, pe = 0.f;
+        int pickc = -1, lastc = 0;
+        float laste = 0.f;
+        for (int c = 0; c < 54; c++) {
+            bool legal = (m >> c) & 1;
+            float e = legal ? __expf(row[c] - mx) : 0.f;
+            acc += e;
+            if (legal) { lastc = c; laste = e; }
+            bool take = legal && pickc < 0 && acc > u;
+            pe = take ? e : pe;
+            pickc = take ? c : pickc;
+        }
+        if (pickc < 0) { pickc = lastc; pe = laste; }
+        action[i] = (uint8_t)pickc;
+        if (logp) logp[i] = __logf(pe / sum);
+    }
+}
+
 __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Aux *__restrict__ aux, u32 *__restrict__ ep,
                                                       int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
@@ -914,6 +1078,19 @@ int tarok_sample_policy(tarok_env *e, const void *logits_bf16, const uint64_t *o
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_sample, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const uint4 *)logits_bf16,
                        (const u64 *)obs, e->gkey, action_out, logp_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *w2, const float *b2, const void *w3,
+                     const float *b3, const uint64_t *obs, uint8_t *action_out, float *logp_out, float *value_out,
+                     void *features_out, void *stream) {
+    if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    dim3 grid((unsigned)((e->n + PM_M - 1) / PM_M));
+    hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
+                       e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
+                       value_out, (uint4 *)features_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

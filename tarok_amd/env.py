@@ -255,6 +255,35 @@ class TarokVecEnv:
             _native.check(self.L.tarok_observe(self._h, self._p(out), self._stream()))
         return out
 
+    @staticmethod
+    def mfma_weight_order(weight):
+        """torch.nn.Linear.weight [out, 256] -> the bf16 fragment order tarok_policy_mlp reads
+        (include/tarok_env.h): [out/32, 16 k-steps, 2 halves, 32 rows, 8] flattened."""
+        out = weight.shape[0]
+        assert weight.shape[1] == 256 and out % 32 == 0
+        return weight.detach().to(torch.bfloat16).view(out // 32, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(out, 256)
+
+    def policy_mlp(self, weights, obs_words, action_out=None, logp_out=None, value_out=None, features_out=None):
+        """Fused learned-policy step (tarok_policy_mlp).  weights = (w1, b1, w2, b2, w3, b3): w* bf16 in
+        mfma_weight_order() ([256,256], [256,256], [64,256]), b* f32; returns (action u8 [N], logp f32 [N],
+        value f32 [N])."""
+        w1, b1, w2, b2, w3, b3 = weights
+        for w, shp in ((w1, (256, 256)), (w2, (256, 256)), (w3, (64, 256))):
+            assert w.dtype == torch.bfloat16 and w.is_contiguous() and tuple(w.shape) == shp
+        for b, k in ((b1, 256), (b2, 256), (b3, 64)):
+            assert b.dtype == torch.float32 and b.is_contiguous() and tuple(b.shape) == (k,)
+        with torch.cuda.device(self.device):
+            if action_out is None:
+                action_out = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+            if logp_out is None:
+                logp_out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            if value_out is None:
+                value_out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+            _native.check(self.L.tarok_policy_mlp(self._h, self._p(w1), self._p(b1), self._p(w2), self._p(b2), self._p(w3),
+                                                  self._p(b3), self._p(obs_words), self._p(action_out), self._p(logp_out),
+                                                  self._p(value_out), self._p(features_out), self._stream()))
+        return action_out, logp_out, value_out
+
     def state(self):
         """Canonical lanes [10,N] (H0-3, P0-3, TAL, META) as host numpy uint64."""
         with torch.cuda.device(self.device):

@@ -26,24 +26,24 @@ from . import sharding
 
 
 class PolicyNet(nn.Module):
-    """256 features -> 2 x hidden ReLU -> 54 card logits + value."""
+    """256 features -> 2 x hidden ReLU -> one 64-wide head: outputs 0..53 = card logits, output
+    54 = state value (the layout tarok_policy_mlp evaluates in one fused MFMA kernel when hidden = 256)."""
 
     def __init__(self, hidden=256):
         super().__init__()
         self.fc1 = nn.Linear(256, hidden)
         self.fc2 = nn.Linear(hidden, hidden)
-        self.pi = nn.Linear(hidden, 64)       # 54 cards, padded to 64 outputs
-        self.v = nn.Linear(hidden, 1)
+        self.head = nn.Linear(hidden, 64)
 
     def forward_raw(self, x):
-        """(logits [N,64] incl. the 10 pad columns, value [N])."""
+        """all 64 head outputs [N,64]"""
         h = F.relu(self.fc1(x))
         h = F.relu(self.fc2(h))
-        return self.pi(h), self.v(h).squeeze(-1)
+        return self.head(h)
 
     def forward(self, x):
-        logits, v = self.forward_raw(x)
-        return logits[..., :54], v
+        out = self.forward_raw(x)
+        return out[..., :54], out[..., 54]
 
 
 def legal_matrix(mask_words):
@@ -106,12 +106,13 @@ class SelfPlay:
     """All four seats of every game share one policy.
 
     The rollout is captured once into a graph (torch.cuda.graph: the library's kernels are
-    launched on torch's capture stream, so they are captured with the GEMMs) and replayed:
-    per lock-step tarok_observe -> 4 bf16 GEMMs -> tarok_sample_policy -> tarok_step, every
-    kernel reading/writing its row of static rollout buffers, no host work in between."""
+    launched on torch's capture stream) and replayed: per lock-step ONE tarok_policy_mlp launch
+    (features -> MLP on the matrix cores -> masked sample, hidden = 256) and one tarok_step
+    launch, both writing straight into their rows of static rollout buffers.  With another
+    hidden size the policy runs as tarok_observe -> torch GEMMs -> tarok_sample_policy."""
 
     def __init__(self, env, hidden=256, lr=3e-4, clip=0.2, vf_coef=0.5, ent_coef=0.01, reward_scale=1.0 / 70.0, seed=0,
-                 use_graph=True):
+                 use_graph=True, fused=None):
         self.env = env
         self.device = env.device
         torch.manual_seed(seed)                       # same initial weights on every rank
@@ -122,18 +123,23 @@ class SelfPlay:
         self.gen.manual_seed(1234 + 7919 * sharding.world()[0])
         self.obs_words = env.reset().words.clone()
         self.use_graph = use_graph
+        self.fused = (hidden == 256) if fused is None else bool(fused)
+        assert not self.fused or hidden == 256, "tarok_policy_mlp is built for hidden = 256"
         self._graph, self._buf, self._T = None, None, 0
-        self._w = None                                # bf16 copies of the weights for the rollout
+        self._w = None                                # rollout copies of the weights (bf16) / biases (f32)
 
-    def _refresh_bf16_weights(self):
+    def _refresh_rollout_weights(self):
         with torch.no_grad():
-            src = [self.net.fc1.weight, self.net.fc1.bias, self.net.fc2.weight, self.net.fc2.bias,
-                   self.net.pi.weight, self.net.pi.bias, self.net.v.weight, self.net.v.bias]
+            n = self.net
+            src = [(n.fc1.weight, torch.bfloat16), (n.fc1.bias, torch.float32), (n.fc2.weight, torch.bfloat16),
+                   (n.fc2.bias, torch.float32), (n.head.weight, torch.bfloat16), (n.head.bias, torch.float32)]
+            conv = (lambda p, dt: self.env.mfma_weight_order(p) if (self.fused and dt == torch.bfloat16)
+                    else p.detach().to(dt).contiguous().clone())
             if self._w is None:
-                self._w = [p.detach().to(torch.bfloat16).clone() for p in src]
+                self._w = [conv(p, dt) for p, dt in src]
             else:
-                for d, p in zip(self._w, src):
-                    d.copy_(p)                        # in place: the captured graph reads these tensors
+                for d, (p, dt) in zip(self._w, src):
+                    d.copy_(conv(p, dt))              # in place: the captured graph reads these tensors
 
     def _alloc(self, T):
         n, dev = self.env.n, self.device
@@ -142,52 +148,53 @@ class SelfPlay:
                          words=torch.empty((T + 1, n), dtype=torch.int64, device=dev),
                          act=torch.empty((T, n), dtype=torch.uint8, device=dev),
                          logp=torch.empty((T, n), dtype=torch.float32, device=dev),
-                         val=torch.empty((T, n, 1), dtype=torch.bfloat16, device=dev),
+                         val=torch.empty((T, n), dtype=torch.float32, device=dev),
                          done=torch.empty((T, n), dtype=torch.uint8, device=dev),
                          reward=torch.zeros((T, n, 4), dtype=torch.int16, device=dev))   # written only where done
         self._graph = None
 
-    def _rollout_body(self, T, prefetch_every):
+    def _rollout_body(self, T):
         env, buf, w = self.env, self._buf, self._w
         for t in range(T):
-            env.observe(buf["obs"][t])
-            h = F.relu(F.linear(buf["obs"][t], w[0], w[1]))
-            h = F.relu(F.linear(h, w[2], w[3]))
-            logits = F.linear(h, w[4], w[5])
-            torch.addmm(w[7], h, w[6].t(), out=buf["val"][t])
-            env.sample_policy(logits, buf["words"][t], buf["act"][t], buf["logp"][t])
+            if self.fused:
+                env.policy_mlp(w, buf["words"][t], buf["act"][t], buf["logp"][t], buf["val"][t], features_out=buf["obs"][t])
+            else:
+                env.observe(buf["obs"][t])
+                h = F.relu(F.linear(buf["obs"][t], w[0], w[1].to(torch.bfloat16)))
+                h = F.relu(F.linear(h, w[2], w[3].to(torch.bfloat16)))
+                out = F.linear(h, w[4], w[5].to(torch.bfloat16))
+                buf["val"][t].copy_(out[:, 54])
+                env.sample_policy(out, buf["words"][t], buf["act"][t], buf["logp"][t])
             env.step(buf["act"][t], auto_reset=True, obs_out=buf["words"][t + 1], reward_out=buf["reward"][t],
                      done_out=buf["done"][t])
-            if (t + 1) % prefetch_every == 0:
-                env.prefetch()
 
     @torch.no_grad()
-    def collect(self, T, prefetch_every=8):
+    def collect(self, T):
         """T lock-steps of self-play into the static rollout buffers."""
         if self._buf is None or self._T != T:
             self._alloc(T)
-        self._refresh_bf16_weights()
+        self._refresh_rollout_weights()
         buf = self._buf
         buf["reward"].zero_()
         buf["words"][0].copy_(self.obs_words)
         if not self.use_graph:
-            self._rollout_body(T, prefetch_every)
+            self._rollout_body(T)
         else:
             if self._graph is None:
                 # warm up outside capture (lazy library / GEMM-workspace initialisation), then restore the env
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(s):
-                    self._rollout_body(min(T, 2), prefetch_every)
+                    self._rollout_body(2)             # an even number of env launches (refill-list parity)
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 torch.cuda.synchronize(self.device)
                 buf["reward"].zero_()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._rollout_body(T, prefetch_every)
+                    self._rollout_body(T)
                 self._graph = g
                 # the capture did not execute anything; continue from the warmed-up env state
-                buf["words"][0].copy_(buf["words"][min(T, 2)])
+                buf["words"][0].copy_(buf["words"][2])
             self._graph.replay()
         self.obs_words = buf["words"][T].clone()
         return buf
@@ -201,7 +208,7 @@ class SelfPlay:
         ret = ret * self.reward_scale
         flat = lambda x: x.reshape(T * n, *x.shape[2:])
         obs, words, act, logp0 = flat(buf["obs"]), flat(words_t), flat(buf["act"]).long(), flat(buf["logp"])
-        val0 = flat(buf["val"]).float().squeeze(-1)
+        val0 = flat(buf["val"]).float()
         ret, known = flat(ret), flat(known)
         adv = ret - val0
         m = known.float()

@@ -476,13 +476,17 @@ def test_selfplay_iteration_runs_and_learns_something_finite(T, S):
     import torch
     from tarok_amd import selfplay as SP
     env = T.TarokVecEnv(4096, seed=1, mix=S.MIX_ALL)
-    sp = SP.SelfPlay(env, hidden=128, seed=0)
-    before = [p.detach().clone() for p in sp.net.parameters()]
-    st = sp.iterate(T=48, epochs=1, minibatches=4)
-    assert np.isfinite(st["loss"]) and st["known_frac"] > 0.3 and st["rollout_steps_per_s"] > 0
-    assert st["env_errors"] == 0
-    assert any((a != b).any().item() for a, b in zip(before, sp.net.parameters()))
-    assert not env.legal_actions().error.any().item()          # the sampled cards were always legal
+    for hidden in (128, 256):                       # torch GEMM path / fused MFMA kernel path
+        sp = SP.SelfPlay(env, hidden=hidden, seed=0)
+        assert sp.fused == (hidden == 256)
+        before = [p.detach().clone() for p in sp.net.parameters()]
+        st = sp.iterate(T=48, epochs=1, minibatches=4)
+        assert np.isfinite(st["loss"]) and st["known_frac"] > 0.3 and st["rollout_steps_per_s"] > 0
+        assert st["env_errors"] == 0
+        assert any((a != b).any().item() for a, b in zip(before, sp.net.parameters()))
+        assert not env.legal_actions().error.any().item()      # the sampled cards were always legal
+        st = sp.iterate(T=48, epochs=1, minibatches=4)           # graph replay
+        assert np.isfinite(st["loss"]) and st["env_errors"] == 0
     env.close()
 
 
@@ -662,3 +666,47 @@ def test_config1_single_klop_game_through_the_main_equivalent(T, O, S):
     # and the Bot players of the reference run through it too
     res = M.main(st_iger=32, iterations=2, seed=1, verbose=False)
     assert len(res) == 2 and all(len(r) == 4 for r in res)
+
+
+def test_fused_policy_mlp_kernel_vs_torch(T, S):
+    """tarok_policy_mlp (features -> 256-256-256-64 MLP on MFMA -> masked sample): features equal
+    tarok_observe's, head outputs equal a float32 torch evaluation of the same bf16 weights within
+    bf16 rounding, actions legal, log-probs consistent with the kernel's own logits."""
+    import torch
+    from tarok_amd import selfplay as SP
+    n = 10000                                        # not a multiple of 64: ragged last workgroup
+    env = T.TarokVecEnv(n, seed=23, mix=S.MIX_ALL)
+    obs = env.reset()
+    for t in range(7):
+        obs, _, _ = env.step(env.policy_random(obs), auto_reset=True)
+    words = obs.words.clone()
+    torch.manual_seed(0)
+    net = SP.PolicyNet(256).cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(3.0)                              # spread the logits a little
+    w = [net.fc1.weight.detach().to(torch.bfloat16).contiguous(), net.fc1.bias.detach().float().contiguous(),
+         net.fc2.weight.detach().to(torch.bfloat16).contiguous(), net.fc2.bias.detach().float().contiguous(),
+         net.head.weight.detach().to(torch.bfloat16).contiguous(), net.head.bias.detach().float().contiguous()]
+    feat = torch.zeros((n, 256), dtype=torch.bfloat16, device="cuda")
+    wk = [env.mfma_weight_order(w[0]), w[1], env.mfma_weight_order(w[2]), w[3], env.mfma_weight_order(w[4]), w[5]]
+    a, logp, val = env.policy_mlp(wk, words, features_out=feat)
+    ref_feat = env.observe()
+    assert (feat == ref_feat).all().item()
+    x = ref_feat.float()
+    h = torch.relu(x @ w[0].float().T + w[1]).to(torch.bfloat16).float()
+    h = torch.relu(h @ w[2].float().T + w[3]).to(torch.bfloat16).float()
+    out = h @ w[4].float().T + w[5]
+    assert (val - out[:, 54]).abs().max().item() < 0.05 * (1 + out[:, 54].abs().max().item())
+    legal = SP.legal_matrix(words & T.karte.OBS_MASK)
+    al = a.long()
+    assert legal.gather(1, al.unsqueeze(1)).all().item()
+    ref_logp = torch.log_softmax(out[:, :54].masked_fill(~legal, float("-inf")), dim=-1).gather(1, al.unsqueeze(1)).squeeze(1)
+    assert (logp - ref_logp).abs().max().item() < 0.08
+    assert (logp - ref_logp).abs().mean().item() < 0.01
+    # same draw as the stand-alone sampler fed with the reference logits, except where rounding moves a boundary
+    pad = torch.zeros((n, 64), dtype=torch.bfloat16, device="cuda")
+    pad[:, :54] = out[:, :54].to(torch.bfloat16)
+    a2, _ = env.sample_policy(pad, words)
+    assert (a2 == a).float().mean().item() > 0.97
+    env.close()
