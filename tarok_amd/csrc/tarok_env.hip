@@ -590,6 +590,14 @@ __device__ __forceinline__ void mlp_layer256(const __bf16 *__restrict__ xin, __b
                                              const __bf16 *__restrict__ w, const float *__restrict__ bias) {
     u32 lane = __lane_id(), wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     u32 n0 = wave * 64;
+    // all 32 weight fragments of this wave's 64-column slab up front (128 VGPRs): one L2 round
+    // trip per layer instead of one per k-step (with 4 MFMAs per k-step there is nothing to hide a
+    // load behind, and the compiler keeps only one step in flight)
+    bf16x8 bw[16][2];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++)
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) bw[kk][nt] = reinterpret_cast<const bf16x8 *>(w)[((wave * 2 + nt) * 16 + kk) * 64 + lane];
     f32x16 acc[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; mt++)
@@ -597,17 +605,21 @@ __device__ __forceinline__ void mlp_layer256(const __bf16 *__restrict__ xin, __b
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int j = 0; j < 16; j++) acc[mt][nt][j] = 0.f;
-#pragma unroll 4
+    // activations from LDS, one k-step ahead of the MFMAs that consume them
+    bf16x8 an[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) an[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 8 * h);
+#pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-        bf16x8 a[2], b[2];
+        bf16x8 a[2] = {an[0], an[1]};
+        if (kk < 15) {
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) a[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 16 * kk + 8 * h);
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) b[nt] = reinterpret_cast<const bf16x8 *>(w)[((wave * 2 + nt) * 16 + kk) * 64 + lane];
+            for (int mt = 0; mt < 2; mt++) an[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 16 * (kk + 1) + 8 * h);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bw[kk][nt], acc[mt][nt], 0, 0, 0);
     }
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) {
@@ -628,7 +640,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
     const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
-    uint4 *__restrict__ features_out) {
+    uint4 *__restrict__ features_out, u64 *__restrict__ stamps) {
+    u64 ts[7];
+#define PM_STAMP(k) if (stamps) ts[k] = __builtin_amdgcn_s_memtime();
+    PM_STAMP(0)
     __shared__ __attribute__((aligned(16))) __bf16 X0[PM_M * PM_LD];
     __shared__ __attribute__((aligned(16))) __bf16 X1[PM_M * PM_LD];
     __shared__ u64 ext[PM_M][4];
@@ -652,39 +667,43 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
         ext[tid][3] = (g.C & ~talon_unowned(g) & ~on_table) | ((u64)(live ? 1u : 0u) << 54);
     }
     __syncthreads();
-    {   // expand to bf16 0.0 / 1.0: thread = (game, 64-feature region), 8 x 16-byte LDS stores
-        u32 gme = tid >> 2, q = tid & 3;
-        u64 wd = ext[gme][q];
+    // expand to bf16 0.0 / 1.0: per iteration 8 games, 32 lanes per game, one 16-byte chunk (8
+    // features = one byte of a feature word) per lane: the optional global copy leaves as full rows
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            u32 byte = (u32)(wd >> (8 * c)) & 255u;
-            uint4 v;
-            v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
-            v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
-            v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
-            v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
-            *reinterpret_cast<uint4 *>(X0 + gme * PM_LD + 64 * q + 8 * c) = v;
-            if (features_out && base + gme < n) features_out[(base + gme) * 32 + q * 8 + c] = v;
-        }
+    for (int it = 0; it < 8; it++) {
+        u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
+        u32 byte = (u32)(ext[gme][chunk >> 3] >> (8 * (chunk & 7))) & 255u;
+        uint4 v;
+        v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
+        v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
+        v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
+        v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+        *reinterpret_cast<uint4 *>(X0 + gme * PM_LD + 8 * chunk) = v;
+        if (features_out && base + gme < n) features_out[(base + gme) * 32 + chunk] = v;
     }
     __syncthreads();
+    PM_STAMP(1)
     mlp_layer256(X0, X1, w1, b1);
     __syncthreads();
+    PM_STAMP(2)
     mlp_layer256(X1, X0, w2, b2);
     __syncthreads();
+    PM_STAMP(3)
     // ---- layer 3: 64 outputs, one 32x32 tile per wave; f32 results to LDS [64][65]
     float *L = reinterpret_cast<float *>(X1);
     {
         u32 lane = __lane_id(), wave = tid >> 6, r = lane & 31, h = lane >> 5;
         u32 mt = wave >> 1, nt = wave & 1;
+        bf16x8 bw[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) bw[kk] = reinterpret_cast<const bf16x8 *>(w3)[(nt * 16 + kk) * 64 + lane];
         f32x16 acc;
 #pragma unroll
         for (int j = 0; j < 16; j++) acc[j] = 0.f;
-#pragma unroll 4
+#pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             bf16x8 a = *reinterpret_cast<const bf16x8 *>(X0 + (32 * mt + r) * PM_LD + 16 * kk + 8 * h);
-            bf16x8 b = reinterpret_cast<const bf16x8 *>(w3)[(nt * 16 + kk) * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[kk], acc, 0, 0, 0);
         }
         u32 ncol = 32 * nt + r;
         float bv = b3[ncol];
@@ -695,35 +714,50 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
         }
     }
     __syncthreads();
+    PM_STAMP(4)
+    if (stamps && tid == 0) {
+        for (int k = 0; k < 5; k++) stamps[blockIdx.x * 8 + k] = ts[k];
+    }
     // ---- masked categorical sample, one lane per game (same draw as k_sample)
     if (tid < PM_M && base + tid < n) {
         int64_t i = base + tid;
-        const float *row = L + tid * 65;
-        if (value) value[i] = row[54];
+        float l[55];
+#pragma unroll
+        for (int c = 0; c < 55; c++) l[c] = L[tid * 65 + c];      // the row into registers: 55 pipelined LDS reads
+        if (value) value[i] = l[54];
         u64 o = obs[i];
         u64 m = o & TAROK_OBS_MASK;
         if (!m) { action[i] = 255; if (logp) logp[i] = 0.f; return; }
         float mx = -3.0e38f;
-        for (int c = 0; c < 54; c++) mx = ((m >> c) & 1) ? fmaxf(mx, row[c]) : mx;
+#pragma unroll
+        for (int c = 0; c < 54; c++) mx = ((m >> c) & 1) ? fmaxf(mx, l[c]) : mx;
         float sum = 0.f;
-        for (int c = 0; c < 54; c++) sum += ((m >> c) & 1) ? __expf(row[c] - mx) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 54; c++) {
+            float e = ((m >> c) & 1) ? __expf(l[c] - mx) : 0.f;
+            l[c] = e;
+            sum += e;
+        }
         u32 rr = rng32(gkey[i], 192u + ((u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u));
         float u = ((float)(rr >> 8) + 0.5f) * (1.0f / 16777216.0f) * sum;
         float acc = 0.f, pe = 0.f;
-        int pickc = -1, lastc = 0;
-        float laste = 0.f;
+        int pickc = -1;
+#pragma unroll
         for (int c = 0; c < 54; c++) {
             bool legal = (m >> c) & 1;
-            float e = legal ? __expf(row[c] - mx) : 0.f;
-            acc += e;
-            if (legal) { lastc = c; laste = e; }
+            acc += l[c];
             bool take = legal && pickc < 0 && acc > u;
-            pe = take ? e : pe;
+            pe = take ? l[c] : pe;
             pickc = take ? c : pickc;
         }
-        if (pickc < 0) { pickc = lastc; pe = laste; }
+        if (pickc < 0) {                   // rounding at the top end: the last legal card
+            pickc = 63 - __clzll(m);
+#pragma unroll
+            for (int c = 0; c < 54; c++) pe = (c == pickc) ? l[c] : pe;
+        }
         action[i] = (uint8_t)pickc;
         if (logp) logp[i] = __logf(pe / sum);
+        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -1090,7 +1124,7 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
     dim3 grid((unsigned)((e->n + PM_M - 1) / PM_M));
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
                        e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
-                       value_out, (uint4 *)features_out);
+                       value_out, (uint4 *)features_out, e->stamps);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

@@ -35,3 +35,16 @@ print("sample_policy:                %.1f us" % bench(lambda: env.sample_policy(
 x = feat
 w0 = net.fc1.weight.detach().to(torch.bfloat16)
 print("one torch linear 256x256:     %.1f us" % bench(lambda: torch.nn.functional.linear(x, w0)))
+# per-phase shader cycles of a workgroup (stamps: diagnostics build path)
+import ctypes as C, numpy as np
+from tarok_amd import _native
+nb = (n + 63) // 64
+st = torch.zeros((max(nb * 8, (n + 63) // 64 * 3), ), dtype=torch.int64, device="cuda")
+_native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
+env.policy_mlp(w, words, a, lp, v, features_out=feat)
+torch.cuda.synchronize()
+_native.check(env.L.tarok_debug_stamps(env._h, None))
+t = st[: nb * 8].view(nb, 8).cpu().numpy()
+d = np.diff(t[:, :6], axis=1)
+print("phase cycles (median over workgroups): features %d, layer1 %d, layer2 %d, layer3 %d, sample %d" % tuple(np.median(d, axis=0)))
+print("total median %d  max %d" % (np.median(t[:, 5] - t[:, 0]), (t[:, 5] - t[:, 0]).max()))
