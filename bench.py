@@ -72,8 +72,9 @@ def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4800)
-    ap.add_argument("--warmup", type=int, default=480)
+    ap.add_argument("--steps", type=int, default=9600, help="timed lock-steps (default ~260 games per slot)")
+    ap.add_argument("--warmup", type=int, default=960, help="untimed lock-steps (default ~26 games per slot)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra timed regions of --steps steps, reported as a spread")
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--prefetch-every", type=int, default=8, help="deal finished slots' next games every k steps")
@@ -149,6 +150,8 @@ def main():
     ev_ms = ev0.elapsed_time(ev1)
     total_steps = n * args.steps * world_size
     value = total_steps / dt
+    # 5 repeats, median (min-max).  `value` stays the first region (the contract's one).
+    spread = [value] + [total_steps / timed(args.steps, cards) for _ in range(max(0, args.repeats - 1))]
     ep, ss = env.counters()
 
     out = {
@@ -166,6 +169,7 @@ def main():
                    "cards_per_launch": cards,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
+        "repeats": {"n": len(spread), "median": sorted(spread)[len(spread) // 2], "min": min(spread), "max": max(spread)},
     }
 
     if rank == 0:
