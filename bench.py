@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="extra timed regions of --steps steps, reported as a spread")
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
     ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
-    ap.add_argument("--prefetch-every", type=int, default=8, help="deal finished slots' next games every k steps")
+    ap.add_argument("--prefetch-every", type=int, default=0,
+                    help="extra synchronous tarok_prefetch every k steps (0: none; the step launches refill the buffers themselves)")
     ap.add_argument("--cards-per-launch", type=int, default=4,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
                          "1 = one card per launch)")
@@ -104,18 +105,20 @@ def main():
     env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
 
     cards = max(1, args.cards_per_launch)
-    pf = max(1, args.prefetch_every)
-    pf = (pf + cards - 1) // cards * cards          # the prefetch period is a whole number of launches
-    if args.steps % cards or args.warmup % cards:
-        raise SystemExit("--steps and --warmup must be multiples of --cards-per-launch (%d)" % cards)
-    # a graph chunk never longer than the timed region, and a multiple of the prefetch period
-    chunk = min(args.graph_chunk, (args.steps // pf) * pf) // pf * pf if args.graph_chunk > 0 else 0
+    pf = max(0, args.prefetch_every)
+    pf = (pf + cards - 1) // cards * cards          # a prefetch period is a whole number of launches
+    # a graph chunk never longer than the timed region, holding an even number of launches
+    q = max(pf, 2 * cards)
+    chunk = min(args.graph_chunk, (args.steps // q) * q) // q * q if args.graph_chunk > 0 else 0
 
     def run(steps, mode):
         """mode: 0 = policy kernel + step kernel, 1 = one card per launch, >= 2 = that many cards per launch"""
-        # the trick-per-launch kernel refills consumed next-game buffers itself: no tarok_prefetch launches
-        env.run_random(steps // max(1, mode) * max(1, mode), cards_per_launch=mode, graph_chunk=chunk, auto_reset=True,
-                       prefetch_every=0 if mode >= 2 else pf)
+        unit = max(1, mode)
+        main = steps // unit * unit
+        if main:
+            env.run_random(main, cards_per_launch=mode, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
+        if steps - main:                                  # K not a multiple of the cards per launch: finish card by card
+            env.run_random(steps - main, cards_per_launch=1, graph_chunk=0, auto_reset=True, prefetch_every=0)
 
     def timed(steps, mode):
         sharding.barrier()
