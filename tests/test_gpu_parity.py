@@ -710,3 +710,101 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
     a2, _ = env.sample_policy(pad, words)
     assert (a2 == a).float().mean().item() > 0.97
     env.close()
+
+
+def test_random_api_sequences_against_an_oracle_model(T, O, S):
+    """Model-based fuzz: a random sequence of API calls (one-card steps with legal / illegal /
+    garbage cards, in-kernel-policy steps, several cards per launch, auto-reset on and off, resets)
+    on the GPU env vs the same sequence applied slot by slot to the CPU oracle; canonical state,
+    observation words, episode numbers and score sums compared after every call."""
+    import ctypes as C
+    rnd = np.random.RandomState(12345)
+    n, seed, mix = 768, 77, S.MIX_ALL
+    L = O.lib()
+    env = T.TarokVecEnv(n, seed=seed, mix=mix)
+
+    class Slot:
+        pass
+    slots = []
+
+    def new_game(sl, ep):
+        sl.ep = ep
+        sl.g = O.Game.synth(seed, sl.i, ep, mix)
+        sl.key = S.game_key(seed, sl.i, ep)
+
+    def model_reset(ep):
+        for sl in slots:
+            new_game(sl, ep)
+            sl.sum = [0, 0, 0, 0]
+            sl.fin = False
+
+    for i in range(n):
+        sl = Slot(); sl.i = i; slots.append(sl)
+    env.reset(episode=0)
+    model_reset(0)
+
+    def model_card(sl, a, auto):
+        """one card (a = None: the Bot policy).  Mirrors k_play's per-card logic."""
+        g = sl.g
+        sl.fin = False
+        if g.g.phase == 2:
+            if a is None:
+                a = L.to_policy_action(sl.key, g.g.trick_no * 4 + g.g.n_in_trick, g.legal())
+            r = g.step(a)
+            if r == 1:
+                sl.fin = True
+                for s in range(4):
+                    sl.sum[s] += g.g.score[s]
+        if auto and g.g.phase == 3:
+            new_game(sl, sl.ep + 1)
+
+    def check(tag):
+        st = env.state()
+        ep, ss = env.counters()
+        words = env.obs_words.cpu().numpy().view(np.uint64)
+        for sl in slots:
+            assert (st[:, sl.i] == sl.g.lanes()).all(), (tag, sl.i)
+            assert ep[sl.i] == sl.ep and list(ss[sl.i]) == sl.sum, (tag, sl.i)
+            assert int(words[sl.i]) == int(L.to_obs_word(C.byref(sl.g.g), 1 if sl.fin else 0)), (tag, sl.i)
+
+    for op in range(140):
+        kind = rnd.choice(["random1", "explicit", "krog", "two_kernel", "reset"], p=[0.25, 0.3, 0.3, 0.12, 0.03])
+        auto = bool(rnd.rand() < 0.7)
+        if kind == "random1":
+            env.step_random(auto_reset=auto)
+            for sl in slots:
+                model_card(sl, None, auto)
+        elif kind == "two_kernel":
+            obs = env.legal_actions()
+            env.step(env.policy_random(obs), auto_reset=auto)
+            for sl in slots:
+                model_card(sl, None, auto)
+        elif kind == "krog":
+            cards = int(rnd.randint(1, 10))
+            env.krog_random(cards, auto_reset=auto)
+            for c in range(cards):
+                for sl in slots:
+                    model_card(sl, None, auto)
+        elif kind == "explicit":
+            acts = np.zeros(n, np.uint8)
+            for sl in slots:
+                m = sl.g.legal()
+                u = rnd.rand()
+                if m and u < 0.85:
+                    ids = [c for c in range(54) if (m >> c) & 1]
+                    acts[sl.i] = ids[rnd.randint(len(ids))]
+                elif u < 0.95:
+                    acts[sl.i] = rnd.randint(0, 54)          # often illegal
+                else:
+                    acts[sl.i] = rnd.randint(54, 256)        # garbage
+            env.step(acts, auto_reset=auto)
+            for sl in slots:
+                model_card(sl, int(acts[sl.i]), auto)
+        else:
+            ep0 = int(rnd.randint(0, 1000))
+            env.reset(episode=ep0)
+            model_reset(ep0)
+            env.legal_actions()
+        if kind != "reset" or True:
+            check((op, kind, auto))
+    env.close()
