@@ -7,13 +7,16 @@
 // HBM bandwidth (no MFMA).
 //
 // Finished games are replaced at once (auto-reset) without a deal on the step's critical path:
-// every slot keeps its next TWO games ready in the buffers of its Aux record (episode e lives in
-// buffer e & 1).  A step that consumes episode k pushes "deal k+2 into buffer k & 1" onto its
+// every slot keeps its next FOUR games ready in the lines of its Aux record (episode e lives in
+// line e & 3).  A launch that consumes episode k pushes "deal k+4 into line k & 3" onto its
 // workgroup's refill list; the NEXT launch carries extra workgroups that work those lists off
 // (sorting-network deals on dense lanes) while its own play workgroups run — the ~4 us of deal
-// latency overlaps the next trick instead of following this one.  Lists are double-buffered by
-// launch parity; a buffer is valid iff its episode tag matches, so a slot that ever finds its
-// buffer missing just deals the game itself, wave-cooperatively (ballot/readlane), same result.
+// latency overlaps the next launch instead of following this one.  Four games ahead let a launch
+// play several tricks (the shortest game, a Berac lost on trick 1, is 4 cards) without ever
+// waiting for a deal.  Lists are double-buffered by launch parity; a line is valid iff its episode
+// tag matches and it is not being re-dealt right now (`cprev` in the slot's state), and a slot
+// that ever finds its line unusable just deals the game itself, wave-cooperatively
+// (ballot/readlane), same result.
 #include "tarok_device.h"
 
 #include <hip/hip_runtime.h>
@@ -25,21 +28,26 @@
 
 #define TK_BLOCK 256
 #define TK_PF_SLOTS 1024
-#define TK_REFILL_CAP 512          // refill-list entries per play workgroup and launch (<= 2 per slot)
+#define TK_REFILL_CAP 1024         // refill-list entries per play workgroup and launch (<= 4 per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 
-// Per-slot side record, two 64-byte lines.  A next-game buffer = the dealt-ahead game's packed
-// pairs, its RNG key and the episode number it is (the validity tag, written last).  Line 0
-// holds everything a finishing game always touches (score sums, episode number) plus buffer 0;
-// line 1 is buffer 1.
-struct __attribute__((aligned(64))) Aux {
-    ulonglong2 n01_0, n23_0; u64 nkey_0; u32 nep_0;   // buffer 0 (even episodes)
-    u32 episode;                                     // episode number of the slot's current game
-    int4 score_sum;                                  // scores summed over finished games, by seat (Tarok.rezultati)
-    ulonglong2 n01_1, n23_1; u64 nkey_1; u32 nep_1;   // buffer 1 (odd episodes)
-    u32 pad[5];
+#define TK_AHEAD 4                  // next-game lines per slot
+// s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
+#define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+// Per-slot side record, four 64-byte lines.  Line b holds the dealt-ahead game whose episode
+// number is b mod 4: its packed pairs, its RNG key and the episode number it is (the validity tag,
+// written last).  The spare 20 bytes of line 0 hold what a finishing game always touches: the
+// slot's episode number and the scores summed over its finished games.
+struct __attribute__((aligned(64))) AuxLine {
+    ulonglong2 n01, n23; u64 nkey; u32 nep;
+    u32 episode;                                     // line 0 only: episode number of the slot's current game
+    int4 score_sum;                                  // line 0 only: summed scores by seat (Tarok.rezultati)
 };
-static_assert(sizeof(Aux) == 128, "Aux must be two cache lines");
+struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
+static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 256, "Aux must be four cache lines");
+#define AUX_EPISODE(a) ((a).line[0].episode)
+#define AUX_SCORES(a) ((a).line[0].score_sum)
 
 struct tarok_env {
     int device;
@@ -48,7 +56,7 @@ struct tarok_env {
     int mix, flags;
     ulonglong2 *s01, *s23;   // packed state
     Aux *aux;                // finish-path record per slot
-    uint8_t *nstale;         // bit0 / bit1: next / next-but-one game missing and not on any refill list
+    uint8_t *nstale;         // bit k: the game k+1 ahead is missing and not on any refill list
                              // (after tarok_reset; what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
@@ -105,9 +113,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     u64 key = game_key(seed, offset + (u64)i, episode);
     u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
     bool bad = false;
-    aux[i].nep_0 = 0xFFFFFFFFu;                 // both next-game buffers: empty
-    aux[i].nep_1 = 0xFFFFFFFFu;
-    nstale[i] = 3;
+#pragma unroll
+    for (int b = 0; b < TK_AHEAD; b++) aux[i].line[b].nep = 0xFFFFFFFFu;   // all next-game lines: empty
+    nstale[i] = (1u << TK_AHEAD) - 1;
     if (deals) {
         const uint8_t *p = deals + i * 54;
         u64 h[4] = {0, 0, 0, 0};
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     }
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 1; g.pend = 0;
+    g.epar = episode & 3; g.cprev = 0;
     if (g.phase == TK_PHASE_EXCHANGE && !(flags & TAROK_DEFER_EXCHANGE)) {
         if (choice && discards) {
             const uint8_t *q = discards + i * 3;
@@ -143,11 +151,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     if (bad) g.error = 1;
     store_game(g, s01, s23, i);
     gkey[i] = key;
-    aux[i].episode = episode;
-    if (flags & TAROK_CLEAR_COUNTERS) aux[i].score_sum = make_int4(0, 0, 0, 0);
+    AUX_EPISODE(aux[i]) = episode;
+    if (flags & TAROK_CLEAR_COUNTERS) AUX_SCORES(aux[i]) = make_int4(0, 0, 0, 0);
 }
 
-// Deal game `episode` of slot j ahead of time into its buffer (episode & 1).
+// Deal game `episode` of slot j ahead of time into its line (episode & 3).
 __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t j, u32 episode, u64 seed, u64 offset, int mix) {
     u64 key = game_key(seed, offset + (u64)j, (u64)episode);
     u64 h0, h1, h2, h3, tal;
@@ -156,43 +164,44 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
     sample_setup(key, mix, c, d, k);
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 1; g.pend = 0;
+    g.epar = episode & 3; g.cprev = 0;
     if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
     ulonglong2 a, b;
     pack(g, a.x, a.y, b.x, b.y);
-    if (episode & 1) { aux[j].n01_1 = a; aux[j].n23_1 = b; aux[j].nkey_1 = key; aux[j].nep_1 = episode; }
-    else             { aux[j].n01_0 = a; aux[j].n23_0 = b; aux[j].nkey_0 = key; aux[j].nep_0 = episode; }
+    AuxLine *ln = &aux[j].line[episode & 3];
+    ln->n01 = a; ln->n23 = b; ln->nkey = key; ln->nep = episode;
 }
 
-// tarok_prefetch: fill, synchronously, the next-game buffers that tarok_reset emptied (flags in
-// nstale: bit0 = episode+1 missing, bit1 = episode+2 missing).  Each workgroup compacts the
-// missing buffers of its 1024-slot tile into an LDS list (4 flag bytes per thread) and deals list
-// entry j on thread j, so the sorting network runs on dense lanes.
+// tarok_prefetch: fill, synchronously, the next-game lines that tarok_reset emptied (flags in
+// nstale: bit k = episode+1+k missing).  Each workgroup compacts the missing lines of its
+// 1024-slot tile into an LDS list (4 flag bytes per thread) and deals list entry j on thread j,
+// so the sorting network runs on dense lanes.
 __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
                                                       Aux *__restrict__ aux, uint8_t *__restrict__ nstale) {
-    __shared__ unsigned short list[2 * TK_PF_SLOTS];
+    __shared__ unsigned short list[TK_AHEAD * TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
     if (threadIdx.x == 0) count = 0;
     __syncthreads();
     u32 f = reinterpret_cast<const u32 *>(nstale + base)[threadIdx.x];   // 4 slots; array is padded
     if (f) {
-        u32 c = __popc(f & 0x03030303u);
+        u32 c = __popc(f & 0x0F0F0F0Fu);
         u32 pos = atomicAdd(&count, c);
 #pragma unroll
         for (u32 k = 0; k < 4; k++) {
-            u32 fk = (f >> (8 * k)) & 3;
-            if (fk & 1) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * 2);
-            if (fk & 2) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * 2 + 1);
+            u32 fk = (f >> (8 * k)) & 15;
+#pragma unroll
+            for (u32 b = 0; b < TK_AHEAD; b++)
+                if (fk & (1u << b)) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * TK_AHEAD + b);
         }
         reinterpret_cast<u32 *>(nstale + base)[threadIdx.x] = 0;
     }
     __syncthreads();
     u32 total = count;
     for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) {
-        int64_t i = base + (list[j] >> 1);
+        int64_t i = base + list[j] / TK_AHEAD;
         if (i >= n) continue;
-        deal_into_buffer(aux, i, aux[i].episode + 1 + (list[j] & 1), seed, offset, mix);
+        deal_into_buffer(aux, i, AUX_EPISODE(aux[i]) + 1 + (list[j] % TK_AHEAD), seed, offset, mix);
     }
 }
 
@@ -303,25 +312,37 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     bool spec = valid && ((g.phase == TK_PHASE_PLAY && (int)g.nt + cards >= 4 &&
                            (berac || (int)(g.trick_no * 4 + g.nt) + cards >= 48)) ||
                           g.phase == TK_PHASE_DONE);
+    // Next-game lines this launch may take: the lines the previous launch put on its refill list
+    // (the `cprev` farthest ahead) are being written by refill workgroups right now.
+    u32 cprev0 = valid ? g.cprev : 0u;
+    u32 allowed = TK_AHEAD - min(cprev0, (u32)TK_AHEAD);
     int4 acc = make_int4(0, 0, 0, 0);
     u32 cur_ep = 0;
-    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
-    u64 nkey = 0;
-    u32 nep = 0xFFFFFFFFu;
+    // (na, nb, nkey): the next game (episode cur_ep + 1), (na2, nb2, nkey2): the one after it; both
+    // are loaded here, before the loop: a load still in flight across loop iterations would make
+    // every iteration wait for the previous iteration's stores (vmcnt counts both, in order)
+    ulonglong2 na = make_ulonglong2(0, 0), nb = na, na2 = na, nb2 = na;
+    u64 nkey = 0, nkey2 = 0;
+    bool ok1 = false, ok2 = false;
     if (spec) {
-        acc = aux[i].score_sum;
-        cur_ep = aux[i].episode;
-        if (autoreset) {
-            if (g.epar) { na = aux[i].n01_0; nb = aux[i].n23_0; nkey = aux[i].nkey_0; nep = aux[i].nep_0; }   // next episode is even
-            else        { na = aux[i].n01_1; nb = aux[i].n23_1; nkey = aux[i].nkey_1; nep = aux[i].nep_1; }
+        acc = AUX_SCORES(aux[i]);
+        cur_ep = AUX_EPISODE(aux[i]);
+        if (autoreset && allowed > 0) {
+            const AuxLine *ln = &aux[i].line[(g.epar + 1) & 3];
+            na = ln->n01; nb = ln->n23; nkey = ln->nkey;
+            u32 nep = ln->nep, nep2 = 0xFFFFFFFFu;
+            if (allowed > 1 && cards > 4) {          // a Berac can be over after 4 cards
+                const AuxLine *l2 = &aux[i].line[(g.epar + 2) & 3];
+                na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey; nep2 = l2->nep;
+            }
+            ok1 = nep == cur_ep + 1;
+            ok2 = nep2 == cur_ep + 2;
         }
     }
-    // (pend: the buffer was put on a refill list by the previous launch together with its
-    //  sibling, i.e. it is being written right now by a refill workgroup: do not look at it)
-    bool was_pend = valid && g.pend != 0;
-    bool have_next = spec && autoreset && !was_pend && nep == cur_ep + 1;
-    g.pend = 0;
+    TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
+    g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
+    bool resync = false;                    // a game was dealt in place: the lines are out of step
     bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
@@ -351,13 +372,22 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
         if (autoreset) {
             bool renew = valid && g.phase == TK_PHASE_DONE;
             if (__ballot(renew)) {
-                bool swapped = false;
-                if (renew && have_next) {
-                    unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game
-                    key = nkey;
-                    have_next = false; swapped = true;
+                if (renew && !resync && !ok1 && consumed >= 1 && consumed < allowed) {
+                    // third game of a launch (or second, when one line was loaded): fetch it now
+                    const AuxLine *ln = &aux[i].line[(cur_ep + 1) & 3];
+                    na = ln->n01; nb = ln->n23; nkey = ln->nkey;
+                    ok1 = ln->nep == cur_ep + 1;
+                    TK_WAIT_LOADS();
                 }
-                bool deal_here = renew && !swapped;          // buffer missing (or 2nd finish of a launch)
+                bool swap = renew && !resync && ok1;
+                if (swap) {
+                    unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game, cprev = 0
+                    key = nkey;
+                    na = na2; nb = nb2; nkey = nkey2;
+                    ok1 = ok2 && consumed + 1 < allowed;
+                    ok2 = false;
+                }
+                bool deal_here = renew && !swap;             // line missing, stale or being re-dealt
                 u64 pend = __ballot(deal_here);
                 if (pend) {
                     u64 dkey = 0;
@@ -377,13 +407,13 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
                         u32 cc, d, k;
                         sample_setup(dkey, mix, cc, d, k);
                         setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
-                        g.epar = (cur_ep + 1) & 1; g.pend = 0;
+                        g.epar = (cur_ep + 1) & 3; g.cprev = 0;
                         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
                         key = dkey;
-                        consumed |= 2;                       // the buffers are out of step: refill both
+                        resync = true;                       // refill all the lines after this launch
                     }
                 }
-                if (renew) { cur_ep++; consumed += 1; seats_dirty = true; }
+                if (renew) { cur_ep++; consumed++; seats_dirty = true; }
             }
         }
         if (RANDOM) legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
@@ -392,20 +422,20 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
             if (done) done[row] = fin ? 1 : 0;
         }
     }
+    // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+4.
+    // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
+    // a game dealt in place: all of them.
+    u32 np = resync ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
     if (valid) {
-        if (consumed > 1) g.pend = 1;        // both buffers go on the list: the next launch must not read them
-        if (acc_dirty) aux[i].score_sum = acc;
-        if (consumed) { aux[i].episode = cur_ep; gkey[i] = key; }
-        if (touched || consumed || was_pend) store_game(g, s01, s23, i, seats_dirty || was_pend);
+        g.cprev = np;                        // the next launch must not read those lines
+        if (acc_dirty) AUX_SCORES(aux[i]) = acc;
+        if (consumed) { AUX_EPISODE(aux[i]) = cur_ep; gkey[i] = key; }
+        if (touched || consumed || cprev0 != np) store_game(g, s01, s23, i, seats_dirty || cprev0 != np);
     }
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
-    // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 and cur+2.
-    // One swap-in leaves cur+1 valid in the other buffer: only cur+2 is new; anything else: both.
-    if (consumed) {
-        u32 np = consumed == 1 ? 1u : 2u;
+    if (valid && np) {
         u32 pos = atomicAdd(&push_count, np);
-        if (np == 2) push_list[pos++] = ((u64)(cur_ep + 1) << 32) | threadIdx.x;
-        push_list[pos] = ((u64)(cur_ep + 2) << 32) | threadIdx.x;
+        for (u32 j = 0; j < np; j++) push_list[pos + j] = ((u64)(cur_ep + TK_AHEAD - j) << 32) | threadIdx.x;
     }
     __syncthreads();
     u32 total = push_count;
@@ -765,8 +795,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Aux *__r
                                                       int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
-    if (ep) ep[i] = aux[i].episode;
-    if (score_sum) score_sum[i] = aux[i].score_sum;
+    if (ep) ep[i] = AUX_EPISODE(aux[i]);
+    if (score_sum) score_sum[i] = AUX_SCORES(aux[i]);
 }
 
 // canonical lanes for parity checks: H0-3, P0-3, TAL, META (tarok_env.h)
@@ -817,7 +847,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.team = (u32)(m >> 42) & 15;
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
-    g.epar = aux[i].episode & 1; g.pend = 0;
+    g.epar = AUX_EPISODE(aux[i]) & 3;
+    g.cprev = (u32)(s23[i].y >> 60) & 7;            // lines on a refill list stay off limits for the next launch
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
     u64 seatc[4];
