@@ -11,11 +11,12 @@ One "step" = one lock-step of every game = one card played in each of the 65,536
 games of a rank (Tarok.py:48-56): legal mask of the seat to move, a uniform random
 legal card (the Bot policy, Igralec.py:158-159), the card applied, trick resolution
 and scoring, finished games replaced at once (auto-reset: every slot is live in
-every step), next observation written.  One kernel launch plays one TRICK (4 such
-steps = one pass of the reference's krog generator) with the state held in
-registers in between and every per-card output written to HBM; state is resident
-in HBM between launches.  value = games x steps x ranks / max-over-ranks time.
-One-card-per-launch and the two-kernel external-policy path are reported beside it.  Weak scaling: each rank owns its own 65,536 games
+every step), next observation written.  One kernel launch plays SIX TRICKS (24 such
+steps; one trick = one pass of the reference's krog generator) with the state held in
+registers in between and every per-card output (action, observation word, done,
+scores) written to HBM; state is resident in HBM between launches.  One trick per
+launch (--cards-per-launch 4) is reported beside it, as are  value = games x steps x ranks / max-over-ranks time.
+one card per launch and the two-kernel external-policy path.  Weak scaling: each rank owns its own 65,536 games
 (global game indices rank*65536...), no collective in the env path.
 
 Extra objects on the JSON line:
@@ -79,9 +80,9 @@ def main():
     ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--prefetch-every", type=int, default=0,
                     help="extra synchronous tarok_prefetch every k steps (0: none; the step launches refill the buffers themselves)")
-    ap.add_argument("--cards-per-launch", type=int, default=4,
+    ap.add_argument("--cards-per-launch", type=int, default=24,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
-                         "1 = one card per launch)")
+                         "24 = six tricks; 1 = one card per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
     args = ap.parse_args()
@@ -130,7 +131,7 @@ def main():
         dt = time.perf_counter() - t0
         return sharding.max_over_ranks([dt])[0]
 
-    # ---- headline: one launch of tarok_krog_random per trick (4 lock-steps): per card legal mask ->
+    # ---- headline: one launch of tarok_krog_random per `cards` lock-steps: per card legal mask ->
     # uniform random legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap ->
     # next observation; state read once and written once per launch, every per-card output
     # (action, observation word, done, scores) written to HBM.  Replayed as a hipGraph of
@@ -168,7 +169,8 @@ def main():
                    "games_per_gpu": n,
                    "mode": "tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's "
                            "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps; "
-                           "finished games' successors are dealt inside the same launch" % (cards, chunk),
+                           "finished games' successors (dealt four games ahead by the refill workgroups of the previous "
+                           "launch) are swapped in inside the same launch" % (cards, chunk),
                    "cards_per_launch": cards,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
@@ -198,8 +200,9 @@ def main():
                            "traffic_source": traffic_src,
                            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us, "steps_per_launch": n * cards,
                            "note": "54 B/step (SURVEY 8d) x %d games x %d cards per launch / (HIP-event time of the timed "
-                                   "region / launches); at this N the per-GPU state (2 MB) is cache resident and the launch "
-                                   "is latency bound: see DESIGN.md for the N-sweep where HBM becomes the limiter"
+                                   "region / launches); at this N the per-GPU state (2 MB) is cache resident and there is one "
+                                   "wave per SIMD: the launch is bound by that wave's instruction issue, see DESIGN.md for "
+                                   "the N-sweep and the VALU-issue ceiling"
                                    % (n, cards)}
 
     if not args.no_extras:
@@ -210,6 +213,13 @@ def main():
         dta = timed(args.steps, 0)
         out["api_two_kernel"] = {"value": total_steps / dta, "unit": "env steps/s", "ms_per_step": dta / args.steps * 1e3,
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
+        # (a'') one trick per launch (tarok_krog_random, 4 cards)
+        if cards != 4:
+            env.reset(episode=0)
+            run(max(args.warmup, chunk), 4)
+            dt4 = timed(args.steps, 4)
+            out["one_trick_per_launch"] = {"value": total_steps / dt4, "unit": "env steps/s", "ms_per_step": dt4 / args.steps * 1e3,
+                                           "note": "tarok_krog_random with 4 cards: 1 launch per trick (one pass of the reference's krog)"}
         # (a') one card per launch with the policy in-kernel (tarok_step_random)
         env.reset(episode=0)
         run(max(args.warmup, chunk), 1)

@@ -136,12 +136,13 @@ int tarok_legal_actions(tarok_env *env, uint64_t *obs_out, int8_t *seat_out, voi
 int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8_t *done_out,
                uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
-/* Fill, synchronously, every next-game buffer that tarok_reset emptied (each slot keeps its next
- * TWO games dealt ahead: episode+1 and episode+2, synthetic contract, Bot exchange).  tarok_reset
- * calls it; afterwards the step kernels keep the buffers full themselves — a step that swaps a
+/* Fill, synchronously, every next-game line that tarok_reset emptied (each slot keeps its next
+ * FOUR games dealt ahead: episode+1 .. episode+4, synthetic contract, Bot exchange).  tarok_reset
+ * calls it; afterwards the step kernels keep the lines full themselves — a launch that swaps a
  * finished game's successor in puts the replacement deal on a list that extra workgroups of the
- * NEXT step launch work off while that step plays — so callers normally never need this.  A slot
- * that finds its buffer missing anyway deals the game inside the step kernel (same result). */
+ * NEXT step launch work off while that launch plays — so callers normally never need this.  A
+ * slot that finds its line missing anyway (more than four games finished within two consecutive
+ * launches) deals the game inside the step kernel (same result). */
 int tarok_prefetch(tarok_env *env, void *stream);
 
 /* Bot_igralec.igraj_karto (Igralec.py:158-159): uniform choice among the legal
@@ -160,7 +161,8 @@ int tarok_step_random(tarok_env *env, uint8_t *action_out, int16_t *reward_out, 
  * reward_out [cards,stride,4] i16 (only where done), done_out, trick_out [cards,stride] u16 and
  * obs_out [cards,stride] u64 is what tarok_step_random would have written for the c-th card.
  * action_out / reward_out / done_out / trick_out may be NULL.  Finished games are replaced at
- * once with TAROK_AUTO_RESET (prefetched buffer first, then dealt in-kernel). */
+ * once with TAROK_AUTO_RESET (from the slot's dealt-ahead lines; a game can be over after 4 cards,
+ * so a slot may start several games inside one launch). */
 int tarok_krog_random(tarok_env *env, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,
                       uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 

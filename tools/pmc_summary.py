@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) into the JSON that
+bench.py reads for roofline.traffic.
+
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <cards_per_launch> <games> <out.json>
+
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  On gfx950 FETCH_SIZE counts a wide
+coalesced read stream at half its bytes (MI355X_MICROARCH.md, rocprofv3/HBM section; calibrated
+here on k_legal, which reads 32 B per game): it is doubled; WRITE_SIZE is exact."""
+import csv, glob, json, os, sys, collections
+
+def collect(d, counter):
+    per = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter:
+                    name = r["Kernel_Name"].split("(")[0]
+                    per[name].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
+    return per
+
+def main():
+    fetch_dir, write_dir, cards, games, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fe) | set(wr)):
+        if not name.startswith(("k_", "void k_")):
+            continue
+        e = {}
+        for cname, per in (("FETCH_SIZE", fe), ("WRITE_SIZE", wr)):
+            v = [x[0] for x in per.get(name, [])]
+            if v:
+                e[cname] = {"launches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
+        kernels[name] = e
+    play = [k for k in kernels if "k_play<true>" in k or "k_playILb1" in k]
+    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
+                     "--steps 960 --warmup 192 --no-cpu-baseline --no-extras (%d cards per launch, %d games); KB per launch "
+                     "as reported; FETCH_SIZE doubled for bytes (gfx950: a wide coalesced read stream is counted at half)" % (cards, games),
+           "kernels": kernels, "games_per_launch": games, "cards_per_launch": cards}
+    if play:
+        # steady-state launches only: the largest launch count belongs to the timed mode
+        k = max(play, key=lambda q: kernels[q].get("FETCH_SIZE", {}).get("launches", 0))
+        f, w = kernels[k]["FETCH_SIZE"]["mean_KB"], kernels[k]["WRITE_SIZE"]["mean_KB"]
+        t = int(round((2 * f + w) * 1024))
+        res["k_play_traffic_bytes_per_launch_cards%d" % cards] = t
+        res["bytes_per_step"] = t / (games * cards)
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
+
+if __name__ == "__main__":
+    main()
