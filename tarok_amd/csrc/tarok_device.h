@@ -78,11 +78,37 @@ __device__ __forceinline__ void pack(const Game &g, u64 &x0, u64 &x1, u64 &y0, u
 
 __device__ __forceinline__ int popc64(u64 m) { return __popcll(m); }
 
+// v_bitop3_b32: any boolean function of three 32-bit words in one instruction.  The immediate
+// is the function's truth table, written here by evaluating it on the three selector bytes.
+template <class F> constexpr u32 tk_tt(F f) { return f(0xF0u, 0xCCu, 0xAAu) & 0xFFu; }
+#define TK_BITOP3(a, b, c, ...) ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), tk_tt([](u32 a_, u32 b_, u32 c_) { return (__VA_ARGS__); })))
+#define TK_LO(x) ((u32)(x))
+#define TK_HI(x) ((u32)((x) >> 32))
+#define TK_U64(lo, hi) (((u64)(u32)(hi) << 32) | (u64)(u32)(lo))
+
 __device__ __forceinline__ u64 seat_cards(const Game &g, u32 s) {
     u64 a = (s & 1) ? g.A : ~g.A, b = (s & 2) ? g.B : ~g.B;
     return a & b & TK_DECK;
 }
-__device__ __forceinline__ u64 hand_of(const Game &g, u32 s) { return seat_cards(g, s) & ~g.C; }
+// hand of seat s = ~C & (A == s&1) & (B == s>>1): with ma / mb = all-ones when the seat bit is
+// set, (A xnor ma) & (B xnor mb) & ~C is two v_bitop3 per 32-bit half
+__device__ __forceinline__ u64 hand_of(const Game &g, u32 s) {
+    u32 ma = (u32)((int)(s << 31) >> 31), mb = (u32)((int)(s << 30) >> 31);
+    u32 tl = TK_BITOP3(TK_LO(g.A), ma, TK_LO(g.C), ~c_ & ~(a_ ^ b_));
+    u32 th = TK_BITOP3(TK_HI(g.A), ma, TK_HI(g.C), ~c_ & ~(a_ ^ b_));
+    u32 hl = TK_BITOP3(tl, TK_LO(g.B), mb, a_ & ~(b_ ^ c_));
+    u32 hh = TK_BITOP3(th, TK_HI(g.B), mb, a_ & ~(b_ ^ c_)) & 0x3FFFFFu;
+    return TK_U64(hl, hh);
+}
+// won pile of seat S (incl. whatever is parked in its pile bits): C & (A == S&1) & (B == S>>1)
+template <int S> __device__ __forceinline__ u64 pile_of(const Game &g) {
+    u32 l, h;
+    if (S == 0)      { l = TK_BITOP3(TK_LO(g.A), TK_LO(g.B), TK_LO(g.C), ~a_ & ~b_ & c_); h = TK_BITOP3(TK_HI(g.A), TK_HI(g.B), TK_HI(g.C), ~a_ & ~b_ & c_); }
+    else if (S == 1) { l = TK_BITOP3(TK_LO(g.A), TK_LO(g.B), TK_LO(g.C), a_ & ~b_ & c_);  h = TK_BITOP3(TK_HI(g.A), TK_HI(g.B), TK_HI(g.C), a_ & ~b_ & c_); }
+    else if (S == 2) { l = TK_BITOP3(TK_LO(g.A), TK_LO(g.B), TK_LO(g.C), ~a_ & b_ & c_);  h = TK_BITOP3(TK_HI(g.A), TK_HI(g.B), TK_HI(g.C), ~a_ & b_ & c_); }
+    else             { l = TK_BITOP3(TK_LO(g.A), TK_LO(g.B), TK_LO(g.C), a_ & b_ & c_);   h = TK_BITOP3(TK_HI(g.A), TK_HI(g.B), TK_HI(g.C), a_ & b_ & c_); }
+    return TK_U64(l, h);
+}
 
 __device__ __forceinline__ u64 ids_mask(u64 ids, int first, int n) {
     u64 m = 0;
@@ -113,22 +139,31 @@ __device__ __forceinline__ u64 talon_unowned(const Game &g) {
 // sum(val) - 2*floor(n/3) - [n%3 != 0].  The values 1..5 are summed as nested
 // popcounts (v_bcnt accumulates for free); n <= 54 so n/3 = (n*43)>>7.
 __device__ __forceinline__ int prestej(u64 m) {
-    u32 n = (u32)popc64(m);
-    u32 v = n + (u32)popc64(m & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + (u32)popc64(m & (TK_V3 | TK_V4 | TK_V5)) +
-            (u32)popc64(m & (TK_V4 | TK_V5)) + (u32)popc64(m & TK_V5);
+    // suits = low word (rank r of a suit is bit r-1 of its byte: ranks 5..8 are worth 2..5),
+    // taroks = high word (pagat, mond, skis = bits 0, 20, 21 are worth 5, the others 1)
+    u32 lo = TK_LO(m), hi = TK_HI(m);
+    u32 n = (u32)__popc(lo) + (u32)__popc(hi);
+    u32 v = n + (u32)__popc(lo & 0xF0F0F0F0u) + (u32)__popc(lo & 0xE0E0E0E0u) + (u32)__popc(lo & 0xC0C0C0C0u) +
+            (u32)__popc(lo & 0x80808080u) + 4u * (u32)__popc(hi & 0x300001u);
     u32 q = (n * 43u) >> 7;
     return (int)(v - 2 * q - (n != 3 * q ? 1u : 0u));
 }
 
 // mozne_karte: Navadna_igra.py:158-168; Klop.py:96-133 adds "pagat only when
 // nothing else is allowed" (the over-play filter there is dead code).
+// The suits are the low word of a plane and the taroks (pagat = bit 0) the high word, so the
+// rule is written on the halves: lead-suit cards if any, else taroks if any, else the hand.
 __device__ __forceinline__ u64 legal_mask(u64 hand, bool has_lead, u32 lead, bool klopfam) {
-    u64 sm = lead >= 32 ? TK_TAROK : (0xFFULL << (8 * (lead >> 3)));
-    u64 s = hand & sm, t = hand & TK_TAROK;
-    u64 follow = s ? s : (t ? t : hand);
-    u64 b = has_lead ? follow : hand;
-    u64 nb = b & ~TK_PAGAT;
-    return (klopfam && nb) ? nb : b;
+    u32 hl = TK_LO(hand), hh = TK_HI(hand);
+    u32 sm = lead < 32 ? (0xFFu << (lead & 24)) : 0u;   // a tarok lead: no suit to follow, taroks next
+    u32 s = hl & sm;
+    bool has_s = has_lead && s != 0;
+    bool has_t = has_lead && hh != 0;
+    u32 bl = has_s ? s : (has_t ? 0u : hl);
+    u32 bh = has_s ? 0u : hh;
+    u32 nh = bh & ~1u;                                  // without the pagat
+    bool drop = klopfam && (bl | nh) != 0;
+    return TK_U64(bl, drop ? nh : bh);
 }
 
 __device__ __forceinline__ u64 legal_now(const Game &g) {
@@ -173,19 +208,27 @@ __device__ __forceinline__ u64 pack_scores(int s0, int s1, int s2, int s3) {
 // so the team pile needs no masking; the rest mask is rebuilt only for :87.
 __device__ __forceinline__ u64 score_game(const Game &g) {
     bool klop = g.contract == TK_KLOP;
-    u64 p0 = seat_cards(g, 0) & g.C, p1 = seat_cards(g, 1) & g.C;
-    u64 p2 = seat_cards(g, 2) & g.C, p3 = seat_cards(g, 3) & g.C;
-    u64 t = ((g.team & 1) ? p0 : 0) | ((g.team & 2) ? p1 : 0) | ((g.team & 4) ? p2 : 0) | ((g.team & 8) ? p3 : 0);
-    u64 kingbit = 1ULL << (g.king * 8 + 7);
-    u64 pd = seat_cards(g, g.declarer) & g.C;
-    bool alone_with_king = !klop && g.contract != TK_SOLO_BREZ && __popc(g.team) == 1 && has_king(g.contract) &&
-                           (pd & kingbit);                                // Navadna_igra.py:87
+    u64 p0 = pile_of<0>(g), p1 = pile_of<1>(g), p2 = pile_of<2>(g), p3 = pile_of<3>(g);
+    // team pile = the taken cards whose owner seat (B_c A_c) is in the team: per card a 4-way
+    // select among the team bits, three bitop3 ("a ? b : c") per half
+    u32 t0 = (u32)((int)(g.team << 31) >> 31), t1 = (u32)((int)(g.team << 30) >> 31);
+    u32 t2 = (u32)((int)(g.team << 29) >> 31), t3 = (u32)((int)(g.team << 28) >> 31);
+    u32 xl = TK_BITOP3(TK_LO(g.A), t1, t0, (a_ & b_) | (~a_ & c_)), yl = TK_BITOP3(TK_LO(g.A), t3, t2, (a_ & b_) | (~a_ & c_));
+    u32 xh = TK_BITOP3(TK_HI(g.A), t1, t0, (a_ & b_) | (~a_ & c_)), yh = TK_BITOP3(TK_HI(g.A), t3, t2, (a_ & b_) | (~a_ & c_));
+    u32 tl = TK_BITOP3(TK_LO(g.B), yl, xl, (a_ & b_) | (~a_ & c_)) & TK_LO(g.C);
+    u32 th = TK_BITOP3(TK_HI(g.B), yh, xh, (a_ & b_) | (~a_ & c_)) & TK_HI(g.C);
+    u64 t = TK_U64(tl, th);
+    // Navadna_igra.py:87: the declarer plays alone (solo, or called a king of his own) and the
+    // called king lies in his pile: the kings are bits 7, 15, 23, 31 of the low word
+    u32 kb = g.king * 8 + 7, d = g.declarer;
+    bool king_taken = ((TK_LO(g.C) >> kb) & 1) && ((TK_LO(g.A) >> kb) & 1) == (d & 1) && ((TK_LO(g.B) >> kb) & 1) == (d >> 1);
+    bool alone_with_king = !klop && g.contract != TK_SOLO_BREZ && __popc(g.team) == 1 && has_king(g.contract) && king_taken;
     if (alone_with_king) t |= talon_unowned(g);
     int c0 = prestej(klop ? p0 : t), c1 = prestej(klop ? p1 : 0), c2 = prestej(klop ? p2 : 0), c3 = prestej(klop ? p3 : 0);
     bool over = c0 > 35 || c1 > 35 || c2 > 35 || c3 > 35;
-    int d = c0 - 35, ad = d < 0 ? -d : d;
+    int d0 = c0 - 35, ad = d0 < 0 ? -d0 : d0;
     int r = 5 * (int)(((u32)(ad + 2) * 205u) >> 10);                     // int(round(d/5))*5, :103
-    if (d < 0) r = -r;
+    if (d0 < 0) r = -r;
     int c = 10 * (int)g.contract;
     int sc = (c0 > 35 ? c : -c) + r;
     int s0 = klop ? (over ? 0 : -c0) : ((g.team & 1) ? sc : 0);
@@ -232,8 +275,11 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
         g.tl--;
         tm |= 1ULL << ((g.talon >> (6 * g.tl)) & 63);
     }
-    g.A = (g.A & ~tm) | ((ws & 1) ? tm : 0);
-    g.B = (g.B & ~tm) | ((ws & 2) ? tm : 0);
+    {   // the trick's cards change owner: plane bit := winner's seat bit where tm is set (one bitop3 per half)
+        u32 m1 = (u32)((int)(ws << 31) >> 31), m2 = (u32)((int)(ws << 30) >> 31);
+        g.A = TK_U64(TK_BITOP3(TK_LO(g.A), TK_LO(tm), m1, (a_ & ~b_) | (b_ & c_)), TK_BITOP3(TK_HI(g.A), TK_HI(tm), m1, (a_ & ~b_) | (b_ & c_)));
+        g.B = TK_U64(TK_BITOP3(TK_LO(g.B), TK_LO(tm), m2, (a_ & ~b_) | (b_ & c_)), TK_BITOP3(TK_HI(g.B), TK_HI(tm), m2, (a_ & ~b_) | (b_ & c_)));
+    }
     // what rezultat_stiha(stih, sem_pobral) is told (Klop.py:76-77, Navadna_igra.py:138-139):
     // Roka.vrednost_stiha of the 4 (Klop: 5) cards (Roka.py:76-95) and who took them
     u32 tv = (u32)(popc64(tm) + popc64(tm & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + popc64(tm & (TK_V3 | TK_V4 | TK_V5)) +
@@ -345,16 +391,22 @@ __device__ __forceinline__ u32 rng32(u32 lo, u32 hi, u32 i) {
 __device__ __forceinline__ u32 rng32(u64 key, u32 i) { return rng32((u32)key, (u32)(key >> 32), i); }
 __device__ __forceinline__ u32 pick(u32 r, u32 n) { return __umulhi(r, n); }
 
-// index of the k-th (0-based) set bit, k < popcount(m): popcount bisection
+// index of the k-th (0-based) set bit, k < popcount(m): bisection on the popcount of a bit
+// field (v_bfe + v_bcnt per level), the window's position carried instead of a shifted copy
 __device__ __forceinline__ u32 kth_bit(u64 m, u32 k) {
-    u32 w = (u32)m, base = 0, c = __popc(w);
-    if (k >= c) { k -= c; w = (u32)(m >> 32); base = 32; }
-    c = __popc(w & 0xFFFF); if (k >= c) { k -= c; w >>= 16; base += 16; }
-    c = __popc(w & 0xFF);   if (k >= c) { k -= c; w >>= 8;  base += 8; }
-    c = __popc(w & 0xF);    if (k >= c) { k -= c; w >>= 4;  base += 4; }
-    c = __popc(w & 0x3);    if (k >= c) { k -= c; w >>= 2;  base += 2; }
-    c = w & 1;              if (k >= c) { base += 1; }
-    return base;
+    u32 c = __popc(TK_LO(m));
+    bool up = k >= c;
+    u32 w = up ? TK_HI(m) : TK_LO(m);
+    k = up ? k - c : k;
+    u32 pos = 0;
+#pragma unroll
+    for (u32 half = 16; half >= 1; half >>= 1) {
+        u32 cc = __popc(__builtin_amdgcn_ubfe(w, pos, half));
+        bool go = k >= cc;
+        k = go ? k - cc : k;
+        pos += go ? half : 0u;
+    }
+    return pos + (up ? 32u : 0u);
 }
 
 // uniform card among the legal ones (Bot_igralec.igraj_karto, Igralec.py:158-159)
