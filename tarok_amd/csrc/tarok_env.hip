@@ -603,69 +603,92 @@ __global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__r
 // (~150 MB of activation traffic per 65,536 games) — the one place in this build where work is
 // GEMM shaped, so the one place that uses the matrix cores.
 //
-// Workgroup = 256 threads = 4 waves, 64 games.  v_mfma_f32_32x32x16_bf16: lane l (r = l & 31,
-// h = l >> 5) holds A[row r][k = 8h..8h+7] and B[k = 8h..8h+7][col r]; D: col = l & 31,
-// row = (reg & 3) + 8 (reg >> 2) + 4 h.  A = activations [game][feature] from LDS (row stride
-// 264 bf16 = 528 B: the 16 lanes of a ds_read_b128 group hit 16 different 4-bank slots),
-// B[k][n] = W[n][k] read straight from the row-major [out][in] weight (16 contiguous bytes per
-// lane, L2 resident).  Layers 1-2: wave w owns output columns [64w, 64w+64) x all 64 games
-// (2x2 tiles, 64 MFMAs); layer 3 (64 outputs = 54 card logits, value in column 54): one 32x32
-// tile per wave.
+// Workgroup = 256 threads = 4 waves, 128 games, ONE activation buffer X[game][feature] in LDS
+// (row stride 264 bf16 = 528 B) updated in place, 72 KB per workgroup: two workgroups share a CU
+// (two waves per SIMD), so one's feature build / epilogues / sampling run under the other's MFMAs.
+// Every layer is computed TRANSPOSED, D[feature][game] = W[feature][k] * X^T[k][game], with
+// v_mfma_f32_32x32x16_bf16: lane l (r = l & 31, h = l >> 5) supplies A[row r][k = 8h..8h+7] = one
+// 16-byte piece of the weight (pre-arranged in fragment order: a wave's load is 1 KiB contiguous)
+// and B[k = 8h..8h+7][col r] = 16 contiguous bytes of game r's row in LDS; it receives
+// D[(reg & 3) + 8 (reg >> 2) + 4 h][col r]: four CONSECUTIVE features of one game per register
+// quad, i.e. one 8-byte LDS store of packed bf16 per quad (the untransposed product scatters 2-byte
+// stores).  Layers 1-2: wave w owns features [64w, 64w+64) x all 128 games (2 x 4 tiles, 128 MFMAs,
+// the weight slab streamed from L2 four k-steps ahead); layer 3 (64 outputs = 54 card logits, value
+// in column 54): wave w owns games [32w, 32w+32).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-#define PM_M 64
+#define PM_M 128
 #define PM_LD 264
+#define PM_LL 68             // f32 logits row stride (272 B: float4 stores stay aligned)
 
-__device__ __forceinline__ void mlp_layer256(const __bf16 *__restrict__ xin, __bf16 *__restrict__ xout,
-                                             const __bf16 *__restrict__ w, const float *__restrict__ bias) {
-    u32 lane = __lane_id(), wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    u32 n0 = wave * 64;
-    // all 32 weight fragments of this wave's 64-column slab up front (128 VGPRs): one L2 round
-    // trip per layer instead of one per k-step (with 4 MFMAs per k-step there is nothing to hide a
-    // load behind, and the compiler keeps only one step in flight)
-    bf16x8 bw[16][2];
+// the weight fragments of a wave's first four k-steps (issued early by the caller: before the
+// feature build for layer 1, before the previous layer's epilogue for layer 2)
+__device__ __forceinline__ void mlp_prefetch(bf16x8 (&wq)[4][2], const __bf16 *__restrict__ w, u32 first_tile) {
+    const bf16x8 *wf = reinterpret_cast<const bf16x8 *>(w) + (size_t)first_tile * 16 * 64 + __lane_id();
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++)
+    for (int d = 0; d < 4; d++)
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) bw[kk][nt] = reinterpret_cast<const bf16x8 *>(w)[((wave * 2 + nt) * 16 + kk) * 64 + lane];
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) acc[mt][nt][j] = 0.f;
-    // activations from LDS, one k-step ahead of the MFMAs that consume them
-    bf16x8 an[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) an[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 8 * h);
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        bf16x8 a[2] = {an[0], an[1]};
-        if (kk < 15) {
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++) an[mt] = *reinterpret_cast<const bf16x8 *>(xin + (32 * mt + r) * PM_LD + 16 * (kk + 1) + 8 * h);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bw[kk][nt], acc[mt][nt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; nt++) {
-        u32 ncol = n0 + 32 * nt + r;
-        float bv = bias[ncol];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                u32 m = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * h;
-                xout[m * PM_LD + ncol] = (__bf16)fmaxf(acc[mt][nt][j] + bv, 0.f);
-            }
-    }
+        for (int ft = 0; ft < 2; ft++) wq[d][ft] = wf[(ft * 16 + d) * 64];
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
+__device__ __forceinline__ void mlp_hidden(__bf16 *__restrict__ X, const __bf16 *__restrict__ w, const float *__restrict__ bias,
+                                           bf16x8 (&wq)[4][2]) {
+    u32 lane = __lane_id(), wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const bf16x8 *wf = reinterpret_cast<const bf16x8 *>(w) + (size_t)(wave * 2) * 16 * 64 + lane;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+        for (int gt = 0; gt < 4; gt++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[ft][gt][j] = 0.f;
+    bf16x8 xn[4];                                      // activations one k-step ahead (wq: weights, 4 k-steps in flight)
+#pragma unroll
+    for (int gt = 0; gt < 4; gt++) xn[gt] = *reinterpret_cast<const bf16x8 *>(X + (32 * gt + r) * PM_LD + 8 * h);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        bf16x8 x[4] = {xn[0], xn[1], xn[2], xn[3]};
+        bf16x8 wc[2] = {wq[kk & 3][0], wq[kk & 3][1]};
+        if (kk + 4 < 16) {
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++) wq[kk & 3][ft] = wf[(ft * 16 + kk + 4) * 64];
+        }
+        if (kk < 15) {
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) xn[gt] = *reinterpret_cast<const bf16x8 *>(X + (32 * gt + r) * PM_LD + 16 * (kk + 1) + 8 * h);
+        }
+#pragma unroll
+        for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) acc[ft][gt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ft], x[gt], acc[ft][gt], 0, 0, 0);
+        // keep the loads issued in this k-step here: left alone, the scheduler sinks each weight
+        // load to just before its use (to save registers) and every k-step waits out an L2 round trip
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                   // every wave has read its last X fragment
+#pragma unroll
+    for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 f0 = wave * 64 + 32 * ft + 8 * q + 4 * h;
+            float4 bv = *reinterpret_cast<const float4 *>(bias + f0);
+#pragma unroll
+            for (int gt = 0; gt < 4; gt++) {
+                bf16x4 o;
+                o[0] = (__bf16)fmaxf(acc[ft][gt][4 * q + 0] + bv.x, 0.f);
+                o[1] = (__bf16)fmaxf(acc[ft][gt][4 * q + 1] + bv.y, 0.f);
+                o[2] = (__bf16)fmaxf(acc[ft][gt][4 * q + 2] + bv.z, 0.f);
+                o[3] = (__bf16)fmaxf(acc[ft][gt][4 * q + 3] + bv.w, 0.f);
+                *reinterpret_cast<bf16x4 *>(X + (32 * gt + r) * PM_LD + f0) = o;
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     int64_t n, const ulonglong2 *__restrict__ s01, const ulonglong2 *__restrict__ s23, const u64 *__restrict__ obs,
     const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
@@ -674,11 +697,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
     u64 ts[7];
 #define PM_STAMP(k) if (stamps) ts[k] = __builtin_amdgcn_s_memtime();
     PM_STAMP(0)
-    __shared__ __attribute__((aligned(16))) __bf16 X0[PM_M * PM_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 X1[PM_M * PM_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 X[PM_M * PM_LD];
     __shared__ u64 ext[PM_M][4];
     int64_t base = (int64_t)blockIdx.x * PM_M;
     u32 tid = threadIdx.x;
+    bf16x8 wq[4][2];
+    mlp_prefetch(wq, w1, (tid >> 6) * 2);           // lands while the features are built
     // ---- the four 64-bit feature words of each game (same definition as k_observe)
     if (tid < PM_M) {
         int64_t i = base + tid < n ? base + tid : n - 1;
@@ -700,7 +724,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
     // expand to bf16 0.0 / 1.0: per iteration 8 games, 32 lanes per game, one 16-byte chunk (8
     // features = one byte of a feature word) per lane: the optional global copy leaves as full rows
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
+    for (int it = 0; it < PM_M / 8; it++) {
         u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
         u32 byte = (u32)(ext[gme][chunk >> 3] >> (8 * (chunk & 7))) & 255u;
         uint4 v;
@@ -708,40 +732,56 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
         v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
         v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
         v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
-        *reinterpret_cast<uint4 *>(X0 + gme * PM_LD + 8 * chunk) = v;
+        *reinterpret_cast<uint4 *>(X + gme * PM_LD + 8 * chunk) = v;
         if (features_out && base + gme < n) features_out[(base + gme) * 32 + chunk] = v;
     }
     __syncthreads();
     PM_STAMP(1)
-    mlp_layer256(X0, X1, w1, b1);
-    __syncthreads();
+    mlp_hidden(X, w1, b1, wq);
     PM_STAMP(2)
-    mlp_layer256(X1, X0, w2, b2);
-    __syncthreads();
+    mlp_prefetch(wq, w2, (tid >> 6) * 2);
+    mlp_hidden(X, w2, b2, wq);
     PM_STAMP(3)
-    // ---- layer 3: 64 outputs, one 32x32 tile per wave; f32 results to LDS [64][65]
-    float *L = reinterpret_cast<float *>(X1);
+    // ---- layer 3: 64 outputs; wave w takes games [32w, 32w+32), both 32-feature tiles; f32
+    // logits to LDS [128][68] over the activation buffer
+    float *L = reinterpret_cast<float *>(X);
     {
         u32 lane = __lane_id(), wave = tid >> 6, r = lane & 31, h = lane >> 5;
-        u32 mt = wave >> 1, nt = wave & 1;
-        bf16x8 bw[16];
+        const bf16x8 *wf = reinterpret_cast<const bf16x8 *>(w3) + lane;
+        f32x16 acc[2];
 #pragma unroll
-        for (int kk = 0; kk < 16; kk++) bw[kk] = reinterpret_cast<const bf16x8 *>(w3)[(nt * 16 + kk) * 64 + lane];
-        f32x16 acc;
+        for (int ft = 0; ft < 2; ft++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = 0.f;
+            for (int j = 0; j < 16; j++) acc[ft][j] = 0.f;
+        bf16x8 wq[4][2];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++) wq[d][ft] = wf[(ft * 16 + d) * 64];
+        bf16x8 xn = *reinterpret_cast<const bf16x8 *>(X + (32 * wave + r) * PM_LD + 8 * h);
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
-            bf16x8 a = *reinterpret_cast<const bf16x8 *>(X0 + (32 * mt + r) * PM_LD + 16 * kk + 8 * h);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bw[kk], acc, 0, 0, 0);
-        }
-        u32 ncol = 32 * nt + r;
-        float bv = b3[ncol];
+            bf16x8 x = xn;
+            bf16x8 wc[2] = {wq[kk & 3][0], wq[kk & 3][1]};
+            if (kk + 4 < 16) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            u32 m = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * h;
-            L[m * 65 + ncol] = acc[j] + bv;
+                for (int ft = 0; ft < 2; ft++) wq[kk & 3][ft] = wf[(ft * 16 + kk + 4) * 64];
+            }
+            if (kk < 15) xn = *reinterpret_cast<const bf16x8 *>(X + (32 * wave + r) * PM_LD + 16 * (kk + 1) + 8 * h);
+#pragma unroll
+            for (int ft = 0; ft < 2; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ft], x, acc[ft], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();                               // all waves are done with X: the logits may overwrite it
+#pragma unroll
+        for (int ft = 0; ft < 2; ft++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32 f0 = 32 * ft + 8 * q + 4 * h;
+                float4 bv = *reinterpret_cast<const float4 *>(b3 + f0);
+                float4 o = make_float4(acc[ft][4 * q + 0] + bv.x, acc[ft][4 * q + 1] + bv.y, acc[ft][4 * q + 2] + bv.z, acc[ft][4 * q + 3] + bv.w);
+                *reinterpret_cast<float4 *>(L + (32 * wave + r) * PM_LL + f0) = o;
+            }
     }
     __syncthreads();
     PM_STAMP(4)
@@ -753,7 +793,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_mlp(
         int64_t i = base + tid;
         float l[55];
 #pragma unroll
-        for (int c = 0; c < 55; c++) l[c] = L[tid * 65 + c];      // the row into registers: 55 pipelined LDS reads
+        for (int c = 0; c < 55; c++) l[c] = L[tid * PM_LL + c];    // the row into registers: 55 pipelined LDS reads
         if (value) value[i] = l[54];
         u64 o = obs[i];
         u64 m = o & TAROK_OBS_MASK;

@@ -38,7 +38,7 @@ print("one torch linear 256x256:     %.1f us" % bench(lambda: torch.nn.functiona
 # per-phase shader cycles of a workgroup (stamps: diagnostics build path)
 import ctypes as C, numpy as np
 from tarok_amd import _native
-nb = (n + 63) // 64
+nb = (n + 127) // 128
 st = torch.zeros((max(nb * 8, (n + 63) // 64 * 3), ), dtype=torch.int64, device="cuda")
 _native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
 env.policy_mlp(w, words, a, lp, v, features_out=feat)
