@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TAROK_ABI_VERSION 1
+#define TAROK_ABI_VERSION 2
 
 #define TAROK_OK 0
 #define TAROK_EINVAL (-1) /* bad argument                                  */
@@ -214,10 +214,14 @@ int tarok_sample_policy(tarok_env *env, const void *logits_bf16, const uint64_t 
  *   W.view(out/32, 32, 16, 2, 8).permute(0, 2, 3, 1, 4) — a wave's weight load is then contiguous;
  *   b1, b2 [256] f32, b3 [64] f32;  obs [N] observation words;
  *   action_out [N] u8, logp_out [N] f32 (may be NULL), value_out [N] f32 (may be NULL),
- *   features_out [N,256] bf16 (may be NULL): the features, for the learner's update. */
+ *   features_out [N,256] bf16 (may be NULL): the features, for the learner's update;
+ *   feature_words_out [N,4] u64 (may be NULL): the same 256 features as bits (feature f = bit
+ *   f % 64 of word f / 64) — 32 bytes per game instead of 512, for a learner that expands its
+ *   minibatches itself. */
 int tarok_policy_mlp(tarok_env *env, const void *w1, const float *b1, const void *w2, const float *b2,
                      const void *w3, const float *b3, const uint64_t *obs, uint8_t *action_out,
-                     float *logp_out, float *value_out, void *features_out, void *stream);
+                     float *logp_out, float *value_out, void *features_out, uint64_t *feature_words_out,
+                     void *stream);
 
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */

@@ -104,7 +104,7 @@ def lib():
     L.tarok_get_state.restype = i32; L.tarok_get_state.argtypes = [vp, vp, vp]
     L.tarok_observe.restype = i32; L.tarok_observe.argtypes = [vp, vp, vp]
     L.tarok_sample_policy.restype = i32; L.tarok_sample_policy.argtypes = [vp, vp, vp, vp, vp, vp]
-    L.tarok_policy_mlp.restype = i32; L.tarok_policy_mlp.argtypes = [vp] * 13
+    L.tarok_policy_mlp.restype = i32; L.tarok_policy_mlp.argtypes = [vp] * 14
     L.tarok_debug_stamps.restype = i32; L.tarok_debug_stamps.argtypes = [vp, vp]
     L.tarok_set_state.restype = i32; L.tarok_set_state.argtypes = [vp, vp, vp]
     L.tarok_get_counters.restype = i32; L.tarok_get_counters.argtypes = [vp, vp, vp, vp]

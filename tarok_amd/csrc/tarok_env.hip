@@ -693,7 +693,7 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
-    uint4 *__restrict__ features_out, u64 *__restrict__ stamps) {
+    uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps) {
     u64 ts[7];
 #define PM_STAMP(k) if (stamps) ts[k] = __builtin_amdgcn_s_memtime();
     PM_STAMP(0)
@@ -719,14 +719,20 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
         ext[tid][1] = (live ? legal_now(g) : 0) | (f1 << 54);
         ext[tid][2] = on_table | (f2 << 54);
         ext[tid][3] = (g.C & ~talon_unowned(g) & ~on_table) | ((u64)(live ? 1u : 0u) << 54);
+        if (feature_words_out && base + tid < n) {
+            feature_words_out[i * 2] = make_ulonglong2(ext[tid][0], ext[tid][1]);
+            feature_words_out[i * 2 + 1] = make_ulonglong2(ext[tid][2], ext[tid][3]);
+        }
     }
     __syncthreads();
+    PM_STAMP(6)
     // expand to bf16 0.0 / 1.0: per iteration 8 games, 32 lanes per game, one 16-byte chunk (8
     // features = one byte of a feature word) per lane: the optional global copy leaves as full rows
+    // (a 256-entry LDS table byte -> 8 bf16 was tried: no faster than the selects)
 #pragma unroll
     for (int it = 0; it < PM_M / 8; it++) {
         u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
-        u32 byte = (u32)(ext[gme][chunk >> 3] >> (8 * (chunk & 7))) & 255u;
+        u32 byte = reinterpret_cast<const uint8_t *>(&ext[gme][0])[chunk];
         uint4 v;
         v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
         v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
@@ -787,46 +793,72 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     PM_STAMP(4)
     if (stamps && tid == 0) {
         for (int k = 0; k < 5; k++) stamps[blockIdx.x * 8 + k] = ts[k];
+        stamps[blockIdx.x * 8 + 6] = ts[6];
     }
-    // ---- masked categorical sample, one lane per game (same draw as k_sample)
-    if (tid < PM_M && base + tid < n) {
-        int64_t i = base + tid;
-        float l[55];
+    // ---- masked categorical sample (same draw, same order of additions as k_sample), two lanes
+    // per game: lane pair (2g, 2g+1) takes cards 0..26 / 27..53, partner values through DPP
+    {
+#define PM_SWAP_F(x) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true))   /* quad_perm [1,0,3,2] */
+#define PM_SWAP_I(x) __builtin_amdgcn_update_dpp(0, (int)(x), 0xB1, 0xF, 0xF, true)
+        u32 gi = tid >> 1, half = tid & 1;
+        bool in_range = base + gi < n;
+        int64_t i = in_range ? base + gi : n - 1;
+        float l[27];
 #pragma unroll
-        for (int c = 0; c < 55; c++) l[c] = L[tid * PM_LL + c];    // the row into registers: 55 pipelined LDS reads
-        if (value) value[i] = l[54];
+        for (int c = 0; c < 27; c++) l[c] = L[gi * PM_LL + 27 * half + c];
+        float v54 = L[gi * PM_LL + 54];
         u64 o = obs[i];
         u64 m = o & TAROK_OBS_MASK;
-        if (!m) { action[i] = 255; if (logp) logp[i] = 0.f; return; }
+        u32 mh = (u32)(m >> (27 * half)) & 0x7FFFFFFu;         // the legality bits of this lane's cards
         float mx = -3.0e38f;
 #pragma unroll
-        for (int c = 0; c < 54; c++) mx = ((m >> c) & 1) ? fmaxf(mx, l[c]) : mx;
-        float sum = 0.f;
+        for (int c = 0; c < 27; c++) mx = ((mh >> c) & 1) ? fmaxf(mx, l[c]) : mx;
+        mx = fmaxf(mx, PM_SWAP_F(mx));
 #pragma unroll
-        for (int c = 0; c < 54; c++) {
-            float e = ((m >> c) & 1) ? __expf(l[c] - mx) : 0.f;
-            l[c] = e;
-            sum += e;
-        }
+        for (int c = 0; c < 27; c++) l[c] = ((mh >> c) & 1) ? __expf(l[c] - mx) : 0.f;
+        // running sums in card order: the low half from 0, then the high half from the low half's total
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 27; c++) s += l[c];
+        float s_sw = PM_SWAP_F(s);                             // (DPP reads need the source lane active: never inside a select)
+        float s_low = half ? s_sw : s;                         // sum over cards 0..26 (in both lanes)
+        float start = half ? s_low : 0.f;
+        float sum = start;
+#pragma unroll
+        for (int c = 0; c < 27; c++) sum += l[c];
+        float sum_sw = PM_SWAP_F(sum);
+        sum = half ? sum : sum_sw;                             // total over cards 0..53, from the high lane
         u32 rr = rng32(gkey[i], 192u + ((u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u));
         float u = ((float)(rr >> 8) + 0.5f) * (1.0f / 16777216.0f) * sum;
-        float acc = 0.f, pe = 0.f;
+        float acc = start, pe = 0.f;
         int pickc = -1;
 #pragma unroll
-        for (int c = 0; c < 54; c++) {
-            bool legal = (m >> c) & 1;
+        for (int c = 0; c < 27; c++) {
+            bool legal = (mh >> c) & 1;
             acc += l[c];
             bool take = legal && pickc < 0 && acc > u;
             pe = take ? l[c] : pe;
             pickc = take ? c : pickc;
         }
-        if (pickc < 0) {                   // rounding at the top end: the last legal card
-            pickc = 63 - __clzll(m);
+        // rounding at the top end: the last legal card (its lane supplies the probability)
+        int last = m ? 63 - __clzll(m) : 0;
+        float pl = 0.f;
 #pragma unroll
-            for (int c = 0; c < 54; c++) pe = (c == pickc) ? l[c] : pe;
+        for (int c = 0; c < 27; c++) pl = (c + 27 * (int)half == last) ? l[c] : pl;
+        int pick_o = PM_SWAP_I(pickc);
+        float pe_o = PM_SWAP_F(pe), pl_o = PM_SWAP_F(pl);
+        if (half == 0 && in_range) {
+            int pk = pickc >= 0 ? pickc : (pick_o >= 0 ? pick_o + 27 : last);
+            float pp = pickc >= 0 ? pe : (pick_o >= 0 ? pe_o : (last < 27 ? pl : pl_o));
+            if (value) value[i] = v54;
+            if (!m) { action[i] = 255; if (logp) logp[i] = 0.f; }
+            else {
+                action[i] = (uint8_t)pk;
+                if (logp) logp[i] = __logf(pp / sum);
+            }
         }
-        action[i] = (uint8_t)pickc;
-        if (logp) logp[i] = __logf(pe / sum);
+#undef PM_SWAP_F
+#undef PM_SWAP_I
         if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
 }
@@ -1189,13 +1221,13 @@ int tarok_sample_policy(tarok_env *e, const void *logits_bf16, const uint64_t *o
 
 int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *w2, const float *b2, const void *w3,
                      const float *b3, const uint64_t *obs, uint8_t *action_out, float *logp_out, float *value_out,
-                     void *features_out, void *stream) {
+                     void *features_out, uint64_t *feature_words_out, void *stream) {
     if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     dim3 grid((unsigned)((e->n + PM_M - 1) / PM_M));
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
                        e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
-                       value_out, (uint4 *)features_out, e->stamps);
+                       value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, e->stamps);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

@@ -263,10 +263,12 @@ class TarokVecEnv:
         assert weight.shape[1] == 256 and out % 32 == 0
         return weight.detach().to(torch.bfloat16).view(out // 32, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(out, 256)
 
-    def policy_mlp(self, weights, obs_words, action_out=None, logp_out=None, value_out=None, features_out=None):
+    def policy_mlp(self, weights, obs_words, action_out=None, logp_out=None, value_out=None, features_out=None,
+                   feature_words_out=None):
         """Fused learned-policy step (tarok_policy_mlp).  weights = (w1, b1, w2, b2, w3, b3): w* bf16 in
         mfma_weight_order() ([256,256], [256,256], [64,256]), b* f32; returns (action u8 [N], logp f32 [N],
-        value f32 [N])."""
+        value f32 [N]).  features_out [N,256] bf16 and/or feature_words_out [N,4] int64 (the same features
+        as bits: expand_feature_words) receive the network input for the learner."""
         w1, b1, w2, b2, w3, b3 = weights
         for w, shp in ((w1, (256, 256)), (w2, (256, 256)), (w3, (64, 256))):
             assert w.dtype == torch.bfloat16 and w.is_contiguous() and tuple(w.shape) == shp
@@ -281,8 +283,16 @@ class TarokVecEnv:
                 value_out = torch.empty(self.n, dtype=torch.float32, device=self.device)
             _native.check(self.L.tarok_policy_mlp(self._h, self._p(w1), self._p(b1), self._p(w2), self._p(b2), self._p(w3),
                                                   self._p(b3), self._p(obs_words), self._p(action_out), self._p(logp_out),
-                                                  self._p(value_out), self._p(features_out), self._stream()))
+                                                  self._p(value_out), self._p(features_out), self._p(feature_words_out),
+                                                  self._stream()))
         return action_out, logp_out, value_out
+
+    @staticmethod
+    def expand_feature_words(words, dtype=torch.bfloat16):
+        """[..., 4] int64 feature words (tarok_policy_mlp feature_words_out) -> [..., 256] 0/1 features."""
+        b = words.contiguous().view(torch.uint8).view(*words.shape[:-1], 32, 1)
+        shifts = torch.arange(8, device=words.device, dtype=torch.uint8)
+        return ((b >> shifts) & 1).view(*words.shape[:-1], 256).to(dtype)
 
     def state(self):
         """Canonical lanes [10,N] (H0-3, P0-3, TAL, META) as host numpy uint64."""

@@ -144,7 +144,11 @@ class SelfPlay:
     def _alloc(self, T):
         n, dev = self.env.n, self.device
         self._T = T
-        self._buf = dict(obs=torch.empty((T, n, 256), dtype=torch.bfloat16, device=dev),
+        # the network input of every step: as 4 x 64 feature bits per game on the fused path (expanded
+        # per minibatch in update()), as [256] bf16 otherwise
+        obs = (torch.empty((T, n, 4), dtype=torch.int64, device=dev) if self.fused
+               else torch.empty((T, n, 256), dtype=torch.bfloat16, device=dev))
+        self._buf = dict(obs=obs,
                          words=torch.empty((T + 1, n), dtype=torch.int64, device=dev),
                          act=torch.empty((T, n), dtype=torch.uint8, device=dev),
                          logp=torch.empty((T, n), dtype=torch.float32, device=dev),
@@ -157,7 +161,7 @@ class SelfPlay:
         env, buf, w = self.env, self._buf, self._w
         for t in range(T):
             if self.fused:
-                env.policy_mlp(w, buf["words"][t], buf["act"][t], buf["logp"][t], buf["val"][t], features_out=buf["obs"][t])
+                env.policy_mlp(w, buf["words"][t], buf["act"][t], buf["logp"][t], buf["val"][t], feature_words_out=buf["obs"][t])
             else:
                 env.observe(buf["obs"][t])
                 h = F.relu(F.linear(buf["obs"][t], w[0], w[1].to(torch.bfloat16)))
@@ -221,8 +225,9 @@ class SelfPlay:
         for _ in range(epochs):
             perm = torch.randperm(T * n, device=self.device, generator=self.gen)
             for idx in perm.chunk(minibatches):
+                x = self.env.expand_feature_words(obs[idx]) if self.fused else obs[idx]
                 with torch.autocast("cuda", dtype=torch.bfloat16):
-                    logits, val = self.net(obs[idx])
+                    logits, val = self.net(x)
                 legal = legal_matrix(words[idx] & K.OBS_MASK)
                 lg = logits.float().masked_fill(~legal, float("-inf"))
                 logp_all = F.log_softmax(lg, dim=-1)

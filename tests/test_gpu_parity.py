@@ -690,9 +690,11 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
          net.head.weight.detach().to(torch.bfloat16).contiguous(), net.head.bias.detach().float().contiguous()]
     feat = torch.zeros((n, 256), dtype=torch.bfloat16, device="cuda")
     wk = [env.mfma_weight_order(w[0]), w[1], env.mfma_weight_order(w[2]), w[3], env.mfma_weight_order(w[4]), w[5]]
-    a, logp, val = env.policy_mlp(wk, words, features_out=feat)
+    fw = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    a, logp, val = env.policy_mlp(wk, words, features_out=feat, feature_words_out=fw)
     ref_feat = env.observe()
     assert (feat == ref_feat).all().item()
+    assert (env.expand_feature_words(fw) == ref_feat).all().item()      # the 32-byte form of the same features
     x = ref_feat.float()
     h = torch.relu(x @ w[0].float().T + w[1]).to(torch.bfloat16).float()
     h = torch.relu(h @ w[2].float().T + w[3]).to(torch.bfloat16).float()

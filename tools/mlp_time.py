@@ -47,4 +47,5 @@ _native.check(env.L.tarok_debug_stamps(env._h, None))
 t = st[: nb * 8].view(nb, 8).cpu().numpy()
 d = np.diff(t[:, :6], axis=1)
 print("phase cycles (median over workgroups): features %d, layer1 %d, layer2 %d, layer3 %d, sample %d" % tuple(np.median(d, axis=0)))
+print("features split: state words %d, expansion %d" % (np.median(t[:, 6] - t[:, 0]), np.median(t[:, 1] - t[:, 6])))
 print("total median %d  max %d" % (np.median(t[:, 5] - t[:, 0]), (t[:, 5] - t[:, 0]).max()))
