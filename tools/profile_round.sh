@@ -21,6 +21,8 @@ for N in 65536 1048576 4194304 16777216; do
   python3 bench.py --games $N --steps 384 --warmup 192 --no-cpu-baseline --no-extras > $OUT/bench_N$N.json 2>> $OUT/nsweep.err || exit 1
   cut -c1-200 $OUT/bench_N$N.json
 done
+bash tools/sq_counters.sh 4194304 $TAG/sq4m > /dev/null 2>&1 && cp gpurun_out/$TAG/sq4m/sq_counters.json $OUT/sq_counters_4194304.json
+python3 tools/mlp_time.py 65536 > $OUT/policy_mlp_times.txt 2>&1
 python3 tools/krog_stamps.py 65536 24 > $OUT/wave_stamps_65536.txt 2>&1
 python3 tools/pf_sweep.py 65536 > $OUT/cards_per_launch_sweep.json 2>&1
 # keep only the summaries of the rocprof directories (the raw traces are large)
