@@ -30,6 +30,9 @@
 #define TK_PF_SLOTS 1024
 #define TK_REFILL_CAP 1024         // refill-list entries per play workgroup and launch (<= 4 per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
+// list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
+// different XCDs, whose L2s are not coherent: two of them must never write into one line
+#define TK_RC(group, par) ((((size_t)(group)) * 2 + (par)) * 32)
 
 #define TK_AHEAD 4                  // next-game lines per slot
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
@@ -37,17 +40,23 @@
 
 // Per-slot side record, four 64-byte lines.  Line b holds the dealt-ahead game whose episode
 // number is b mod 4: its packed pairs, its RNG key and the episode number it is (the validity tag,
-// written last).  The spare 20 bytes of line 0 hold what a finishing game always touches: the
-// slot's episode number and the scores summed over its finished games.
+// written last).
 struct __attribute__((aligned(64))) AuxLine {
     ulonglong2 n01, n23; u64 nkey; u32 nep;
-    u32 episode;                                     // line 0 only: episode number of the slot's current game
-    int4 score_sum;                                  // line 0 only: summed scores by seat (Tarok.rezultati)
+    u32 pad[5];
 };
 struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
 static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 256, "Aux must be four cache lines");
-#define AUX_EPISODE(a) ((a).line[0].episode)
-#define AUX_SCORES(a) ((a).line[0].score_sum)
+// What a finishing game always touches: the slot's episode number and its summed scores.  Kept
+// apart from the next-game lines: those are written by refill workgroups, these by the slot's own
+// play workgroup, which runs on another XCD (another, non-coherent L2) — the two must not share
+// a cache line.
+struct __attribute__((aligned(32))) Counters {
+    int4 score_sum;                                  // summed scores by seat (Tarok.rezultati)
+    u32 episode;                                     // episode number of the slot's current game
+    u32 pad[3];
+};
+static_assert(sizeof(Counters) == 32, "Counters is half a cache line");
 
 struct tarok_env {
     int device;
@@ -55,7 +64,8 @@ struct tarok_env {
     u64 offset, seed;
     int mix, flags;
     ulonglong2 *s01, *s23;   // packed state
-    Aux *aux;                // finish-path record per slot
+    Aux *aux;                // next-game lines per slot
+    Counters *cnt;           // episode number and score sums per slot
     uint8_t *nstale;         // bit k: the game k+1 ahead is missing and not on any refill list
                              // (after tarok_reset; what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     int64_t n, u64 seed, u64 offset, u32 episode, int mix, int flags,
     const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
     const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -151,8 +161,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     if (bad) g.error = 1;
     store_game(g, s01, s23, i);
     gkey[i] = key;
-    AUX_EPISODE(aux[i]) = episode;
-    if (flags & TAROK_CLEAR_COUNTERS) AUX_SCORES(aux[i]) = make_int4(0, 0, 0, 0);
+    cnt[i].episode = episode;
+    if (flags & TAROK_CLEAR_COUNTERS) cnt[i].score_sum = make_int4(0, 0, 0, 0);
 }
 
 // Deal game `episode` of slot j ahead of time into its line (episode & 3).
@@ -177,7 +187,8 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
 // 1024-slot tile into an LDS list (4 flag bytes per thread) and deals list entry j on thread j,
 // so the sorting network runs on dense lanes.
 __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
-                                                      Aux *__restrict__ aux, uint8_t *__restrict__ nstale) {
+                                                      Aux *__restrict__ aux, const Counters *__restrict__ cnt,
+                                                      uint8_t *__restrict__ nstale) {
     __shared__ unsigned short list[TK_AHEAD * TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
     for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) {
         int64_t i = base + list[j] / TK_AHEAD;
         if (i >= n) continue;
-        deal_into_buffer(aux, i, AUX_EPISODE(aux[i]) + 1 + (list[j] % TK_AHEAD), seed, offset, mix);
+        deal_into_buffer(aux, i, cnt[i].episode + 1 + (list[j] % TK_AHEAD), seed, offset, mix);
     }
 }
 
@@ -264,8 +275,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, u64 *__restrict__ gkey,
-    u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
     if (blockIdx.x >= play_groups) {
         // ---- refill role: the lists the previous launch wrote for `fan` play workgroups,
         // concatenated so that the sorting-network deals run on dense lanes (~11 % of the slots
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
         cum[0] = 0;
 #pragma unroll
         for (u32 q = 0; q < TK_REFILL_FAN; q++)
-            cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[(g0 + q) * 2 + (par ^ 1)] : 0u);
+            cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[TK_RC(g0 + q, par ^ 1)] : 0u);
         for (u32 j = threadIdx.x; j < cum[TK_REFILL_FAN]; j += TK_BLOCK) {
             u32 q = 0;
 #pragma unroll
@@ -325,8 +336,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     u64 nkey = 0, nkey2 = 0;
     bool ok1 = false, ok2 = false;
     if (spec) {
-        acc = AUX_SCORES(aux[i]);
-        cur_ep = AUX_EPISODE(aux[i]);
+        acc = cnt[i].score_sum;
+        cur_ep = cnt[i].episode;
         if (autoreset && allowed > 0) {
             const AuxLine *ln = &aux[i].line[(g.epar + 1) & 3];
             na = ln->n01; nb = ln->n23; nkey = ln->nkey;
@@ -428,8 +439,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     u32 np = resync ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
     if (valid) {
         g.cprev = np;                        // the next launch must not read those lines
-        if (acc_dirty) AUX_SCORES(aux[i]) = acc;
-        if (consumed) { AUX_EPISODE(aux[i]) = cur_ep; gkey[i] = key; }
+        if (acc_dirty) cnt[i].score_sum = acc;
+        if (consumed) { cnt[i].episode = cur_ep; gkey[i] = key; }
         if (touched || consumed || cprev0 != np) store_game(g, s01, s23, i, seats_dirty || cprev0 != np);
     }
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     u32 total = push_count;
     u64 *lst = rlist + ((int64_t)blockIdx.x * 2 + par) * TK_REFILL_CAP;
     for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) lst[j] = push_list[j];
-    if (threadIdx.x == 0) rcount[blockIdx.x * 2 + par] = total;
+    if (threadIdx.x == 0) rcount[TK_RC(blockIdx.x, par)] = total;
     if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics only
         u64 w = (u64)i >> 6;
         stamps[3 * w + 0] = t_real0;
@@ -863,12 +874,12 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     }
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Aux *__restrict__ aux, u32 *__restrict__ ep,
+__global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
                                                       int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
-    if (ep) ep[i] = AUX_EPISODE(aux[i]);
-    if (score_sum) score_sum[i] = AUX_SCORES(aux[i]);
+    if (ep) ep[i] = cnt[i].episode;
+    if (score_sum) score_sum[i] = cnt[i].score_sum;
 }
 
 // canonical lanes for parity checks: H0-3, P0-3, TAL, META (tarok_env.h)
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglo
 // talon to where setup_game parks it.
 __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__restrict__ in,
                                                        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23,
-                                                       const Aux *__restrict__ aux) {
+                                                       const Counters *__restrict__ cnt) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 m = in[9 * n + i];
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.team = (u32)(m >> 42) & 15;
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
-    g.epar = AUX_EPISODE(aux[i]) & 3;
+    g.epar = cnt[i].episode & 3;
     g.cprev = (u32)(s23[i].y >> 60) & 7;            // lines on a refill list stay off limits for the next launch
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
@@ -985,15 +996,17 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->aux, (size_t)n_games * sizeof(Aux));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->cnt, (size_t)n_games * sizeof(Counters));
     if (r == hipSuccess) r = hipMalloc((void **)&e->nstale, stale_bytes);
     if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, groups * 2 * sizeof(u32));
-    if (r == hipSuccess) r = hipMemset(e->rcount, 0, groups * 2 * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->aux, 0, (size_t)n_games * sizeof(Aux));
+    if (r == hipSuccess) r = hipMemset(e->cnt, 0, (size_t)n_games * sizeof(Counters));
     if (r == hipSuccess) r = hipMemset(e->nstale, 0, stale_bytes);
     if (r == hipSuccess) r = hipMemset(e->gkey, 0, (size_t)n_games * sizeof(u64));
     if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking);
@@ -1011,7 +1024,7 @@ void tarok_destroy(tarok_env *e) {
     (void)hipSetDevice(e->device);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
+    (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
     (void)hipFree(e->rlist); (void)hipFree(e->rcount);
     delete e;
 }
@@ -1020,7 +1033,7 @@ int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
 
 static inline void launch_prefetch(tarok_env *e, hipStream_t s) {
     dim3 grid((unsigned)((e->n + TK_PF_SLOTS - 1) / TK_PF_SLOTS));
-    hipLaunchKernelGGL(k_prefetch, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, e->aux, e->nstale);
+    hipLaunchKernelGGL(k_prefetch, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, e->aux, e->cnt, e->nstale);
 }
 
 int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8_t *contract, const int8_t *declarer,
@@ -1029,10 +1042,10 @@ int tarok_reset(tarok_env *e, uint32_t episode, const uint8_t *deals, const int8
     if ((talon_choice == nullptr) != (discards == nullptr)) return TAROK_EINVAL;
     if (contract && !declarer) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipMemsetAsync(e->rcount, 0, (size_t)((e->n + TK_BLOCK - 1) / TK_BLOCK) * 2 * sizeof(u32), (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(e->rcount, 0, TK_RC((e->n + TK_BLOCK - 1) / TK_BLOCK, 0) * sizeof(u32), (hipStream_t)stream));
     hipLaunchKernelGGL(k_reset, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset,
                        episode, e->mix, flags, deals, contract, declarer, king_suit, talon_choice, discards, e->s01,
-                       e->s23, e->aux, e->nstale, e->gkey);
+                       e->s23, e->aux, e->cnt, e->nstale, e->gkey);
     launch_prefetch(e, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
@@ -1076,11 +1089,11 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     if (random)
         hipLaunchKernelGGL(k_play<true>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
                            groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
-                           e->gkey, e->rlist, e->rcount, e->stamps);
+                           e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
     else
         hipLaunchKernelGGL(k_play<false>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
                            groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
-                           e->gkey, e->rlist, e->rcount, e->stamps);
+                           e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
@@ -1245,7 +1258,7 @@ int tarok_set_state(tarok_env *e, const uint64_t *lanes_in, void *stream) {
     if (!e || !lanes_in) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_set_state, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const u64 *)lanes_in,
-                       e->s01, e->s23, e->aux);
+                       e->s01, e->s23, e->cnt);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -1253,7 +1266,7 @@ int tarok_set_state(tarok_env *e, const uint64_t *lanes_in, void *stream) {
 int tarok_get_counters(tarok_env *e, uint32_t *episode_out, int32_t *score_sum_out, void *stream) {
     if (!e) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_counters, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->aux, episode_out,
+    hipLaunchKernelGGL(k_counters, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->cnt, episode_out,
                        (int4 *)score_sum_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;

@@ -265,7 +265,8 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
     for cards, chunk, pf in [(0, 48, 4), (1, 0, 0), (1, 64, 16), (0, 0, 2),
-                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0), (8, 64, 0), (12, 48, 0)]:
+                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0), (8, 64, 0), (12, 48, 0),
+                             (24, 192, 0), (24, 96, 0), (32, 192, 0)]:       # 24 / 192 / 0 is the bench's headline mode
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
@@ -283,13 +284,13 @@ def test_krog_kernel_writes_what_four_single_steps_write(T, S):
     call writes (actions, observation words, done, per-trick info, scores), with and without
     auto-reset, from aligned and mid-trick starts."""
     n = 16384
-    for auto, cards, lead_in in [(True, 4, 0), (True, 4, 2), (False, 4, 0), (True, 8, 1), (True, 5, 0)]:
+    for auto, cards, lead_in in [(True, 4, 0), (True, 4, 2), (False, 4, 0), (True, 8, 1), (True, 5, 0), (True, 24, 0), (True, 24, 3)]:
         a = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         b = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         a.reset(); b.reset()
         for t in range(lead_in):
             a.step_random(auto_reset=auto); b.step_random(auto_reset=auto)
-        for rounds in range(14):
+        for rounds in range(14 if cards < 24 else 6):
             kb = a.krog_random(cards, auto_reset=auto)
             for c in range(cards):
                 ob, rw, dn = b.step_random(auto_reset=auto, tricks=True)
@@ -616,6 +617,23 @@ def test_four_million_games_rollout_bit_exact(T, O, S):
     ref = O.rollout(77, 123456789, n, 2, S.MIX_ALL, threads=16, trace=False)
     assert (out["nsteps"].cpu().numpy() == ref["nsteps"]).all()
     assert (out["scores"].cpu().numpy() == ref["scores"]).all()
+    env.close()
+
+
+def test_million_games_headline_mode_vs_oracle(T, O, S):
+    """The bench's mode (24 cards per launch, graph-replayed, auto-reset) on 2^20 games of a shard
+    that does not start at game 0: episode numbers, score sums, canonical state and observation
+    words after 96 lock-steps vs the oracle."""
+    n, seed, steps, off = 1 << 20, 5, 96, 987654321
+    ref = O.run_autoreset(seed, off, n, S.MIX_ALL, steps)
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, game_offset=off)
+    env.reset()
+    env.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+    ep, ss = env.counters()
+    assert (ep == ref["episode"]).all()
+    assert (ss == ref["score_sum"]).all()
+    assert (env.state() == ref["lanes"]).all()
+    assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all()
     env.close()
 
 
