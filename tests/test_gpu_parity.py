@@ -283,8 +283,10 @@ def test_krog_kernel_writes_what_four_single_steps_write(T, S):
     """tarok_krog_random(cards): row c of every output equals what the c-th tarok_step_random
     call writes (actions, observation words, done, per-trick info, scores), with and without
     auto-reset, from aligned and mid-trick starts."""
-    n = 16384
-    for auto, cards, lead_in in [(True, 4, 0), (True, 4, 2), (False, 4, 0), (True, 8, 1), (True, 5, 0), (True, 24, 0), (True, 24, 3)]:
+    # (the last case: more workgroups than fit on the chip at once and an N that puts workgroup
+    #  boundaries inside cache lines of the byte-sized output rows)
+    for auto, cards, lead_in, n in [(True, 4, 0, 16384), (True, 4, 2, 16384), (False, 4, 0, 16384), (True, 8, 1, 16384),
+                                    (True, 5, 0, 16384), (True, 24, 0, 16384), (True, 24, 3, 16384), (True, 24, 0, 300007)]:
         a = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         b = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         a.reset(); b.reset()
@@ -635,6 +637,30 @@ def test_million_games_headline_mode_vs_oracle(T, O, S):
     assert (env.state() == ref["lanes"]).all()
     assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all()
     env.close()
+
+
+def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S):
+    """2^22 games, 24 cards per launch, 96 lock-steps: two runs give identical counters and state
+    (no launch-order or cache-placement dependence), and the third quarter of the batch equals a
+    2^20-game env created on that shard alone."""
+    n, steps = 1 << 22, 96
+    res = []
+    for rep in range(2):
+        env = T.TarokVecEnv(n, seed=9, mix=S.MIX_ALL)
+        env.reset()
+        env.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+        ep, ss = env.counters()
+        res.append((ep.copy(), ss.copy(), env.state().copy()))
+        env.close()
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()
+    q = n // 4
+    part = T.TarokVecEnv(q, seed=9, mix=S.MIX_ALL, game_offset=2 * q)
+    part.reset()
+    part.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+    ep, ss = part.counters()
+    assert (ep == res[0][0][2 * q:3 * q]).all() and (ss == res[0][1][2 * q:3 * q]).all()
+    assert (part.state() == res[0][2][:, 2 * q:3 * q]).all()
+    part.close()
 
 
 def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S):
