@@ -25,6 +25,38 @@ from . import karte as K
 from . import sharding
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient is computed as a batch of partial products.
+
+    dW = dY^T X has M = N = 256 or 64 and K = the minibatch (393,216 rows in the bench): as ONE
+    GEMM it has 16 output tiles, i.e. 240 of the 256 CUs idle (hipBLASLt picks a 64x64x256 tile:
+    0.81 ms, 2.5 % of the matrix peak, 44 % of the whole update).  Split along K into S batches
+    (torch.bmm) it is S x 16 tiles; the partials are summed in f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        cd = torch.bfloat16 if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+        with torch.autocast(x.device.type, enabled=False):
+            xq, wq = x.to(cd), w.to(cd)
+            ctx.save_for_backward(xq, wq)
+            ctx.out_dtypes = (x.dtype, w.dtype, b.dtype)
+            return F.linear(xq, wq, b.to(cd))
+
+    @staticmethod
+    def backward(ctx, gy):
+        xq, wq = ctx.saved_tensors
+        dx, dw, db = ctx.out_dtypes
+        gy = gy.contiguous()
+        gx = (gy @ wq).to(dx) if ctx.needs_input_grad[0] else None
+        B = xq.shape[0]
+        S = next((s for s in (128, 96, 64, 48, 32, 24, 16, 8, 4, 2) if B % s == 0 and B // s >= 512), 1)
+        if S > 1:
+            gw = torch.bmm(gy.view(S, B // S, -1).transpose(1, 2), xq.view(S, B // S, -1)).float().sum(0)
+        else:
+            gw = (gy.t() @ xq).float()
+        return gx, gw.to(dw), gy.float().sum(0).to(db)
+
+
 class PolicyNet(nn.Module):
     """256 features -> 2 x hidden ReLU -> one 64-wide head: outputs 0..53 = card logits, output
     54 = state value (the layout tarok_policy_mlp evaluates in one fused MFMA kernel when hidden = 256)."""
@@ -37,9 +69,13 @@ class PolicyNet(nn.Module):
 
     def forward_raw(self, x):
         """all 64 head outputs [N,64]"""
-        h = F.relu(self.fc1(x))
-        h = F.relu(self.fc2(h))
-        return self.head(h)
+        if x.dim() == 2 and x.shape[0] >= 16384 and torch.is_grad_enabled():    # a training minibatch
+            lin = lambda m, t: _LinearSplitK.apply(t, m.weight, m.bias)
+        else:
+            lin = lambda m, t: m(t)
+        h = F.relu(lin(self.fc1, x))
+        h = F.relu(lin(self.fc2, h))
+        return lin(self.head, h)
 
     def forward(self, x):
         out = self.forward_raw(x)
