@@ -20,9 +20,13 @@ def child(n, off, cards, steps, chunk):
 if sys.argv[1] == "child":
     child(*[int(x) for x in sys.argv[2:7]])
 else:
-    for n, off, cards, steps, chunk, fan in [(1 << 20, 987654321, 24, 96, 48, None), (1 << 20, 0, 24, 96, 48, None), (1 << 20, 0, 24, 96, 48, "1"),
-                                             (1 << 18, 0, 24, 96, 48, None), (1 << 17, 0, 24, 96, 48, None), (1 << 17, 0, 24, 96, 48, "8"),
-                                             (1 << 20, 0, 4, 96, 48, None), (1 << 20, 0, 24, 96, 0, None), (1 << 20, 0, 24, 48, 0, None)]:
+    cases = [(1 << 20, 987654321, 24, 96, 48, None), (1 << 20, 0, 24, 96, 48, None), (1 << 20, 0, 24, 96, 48, "1"),
+             (1 << 18, 0, 24, 96, 48, None), (1 << 17, 0, 24, 96, 48, None), (1 << 17, 0, 24, 96, 48, "8"),
+             (1 << 20, 0, 4, 96, 48, None), (1 << 20, 0, 24, 96, 0, None), (1 << 20, 0, 24, 48, 0, None),
+             # one card per launch, the two-kernel external-policy path, ragged N
+             (1 << 20, 0, 1, 96, 48, None), (1 << 20, 0, 0, 96, 48, None), (1 << 20, 5, 0, 64, 0, None),
+             (1000003, 77, 24, 96, 48, None), (1000003, 77, 1, 64, 0, None), (1 << 22, 0, 24, 48, 48, None)]
+    for n, off, cards, steps, chunk, fan in cases:
         env = dict(os.environ)
         if fan: env["TAROK_REFILL_FAN"] = fan
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(n), str(off), str(cards), str(steps), str(chunk)], env=env, capture_output=True, text=True)
