@@ -223,6 +223,23 @@ int tarok_policy_mlp(tarok_env *env, const void *w1, const float *b1, const void
                      float *logp_out, float *value_out, void *features_out, uint64_t *feature_words_out,
                      void *stream);
 
+/* The learner's loss for the policy above, forward and gradient in one pass: clipped-surrogate
+ * policy loss + value loss - entropy bonus over the LEGAL cards of every sample (build-owned:
+ * the reference has no policy-gradient learner).
+ *   out_bf16 [B,64] bf16 head outputs (0..53 card logits, 54 value), obs [B] observation words
+ *   (legal mask), action [B] i64 the card played, logp_old [B] f32 its log-probability at play
+ *   time, advantage / ret / weight [B] f32 (weight 0: sample ignored);
+ *   loss = sum_i w_i (-min(r_i A_i, clamp(r_i, 1-clip, 1+clip) A_i) + vf (v_i - ret_i)^2 - ent H_i)
+ *          * inv_weight_sum[0] (a device scalar, so that no host round trip sits between the
+ *          minibatch's weight sum and this launch),   r_i = exp(logp_i[a_i] - logp_old_i), H_i the
+ *          entropy of the masked softmax;
+ *   dout_bf16 [B,64] bf16 = d loss / d out;  partial_out [ceil(B/256),4] f32 = per-workgroup sums of
+ *   {w pi, w (v-ret)^2, w H, 0} (sum them for the loss terms). */
+int tarok_ppo_loss(tarok_env *env, int64_t n_samples, const void *out_bf16, const uint64_t *obs,
+                   const int64_t *action, const float *logp_old, const float *advantage, const float *ret,
+                   const float *weight, float clip, float vf_coef, float ent_coef, const float *inv_weight_sum,
+                   void *dout_bf16, float *partial_out, void *stream);
+
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */
 int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);

@@ -606,6 +606,116 @@ __global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__r
 
 
 // ---------------------------------------------------------------------------
+// Learner side of the policy step: the clipped-surrogate policy-gradient loss
+// over the LEGAL cards, forward and gradient in one pass over the head outputs.  Replaces ~40
+// framework elementwise kernels per minibatch (bit-expand of the mask, masked_fill, log_softmax,
+// gather, exp, clamp, min, entropy, their backward kernels) with one read of [B,64] bf16 and one
+// write of the same shape.
+//   out [B,64] bf16: columns 0..53 card logits, column 54 the state value.
+//   per sample: pi = -min(r A, clamp(r, 1-eps, 1+eps) A) with r = exp(logp[a] - logp_old),
+//               v = (value - ret)^2,  H = -sum p log p over the legal cards;
+//   loss = sum_i w_i (pi_i + vf v_i - ent H_i) / wsum.
+// dout = d loss / d out (bf16); part[block] = {sum w pi, sum w v, sum w H, 0} (f32, unscaled).
+__global__ __launch_bounds__(TK_BLOCK) void k_ppo_loss(int64_t n, const uint4 *__restrict__ out, const u64 *__restrict__ words,
+                                                      const int64_t *__restrict__ act, const float *__restrict__ logp_old,
+                                                      const float *__restrict__ adv, const float *__restrict__ ret,
+                                                      const float *__restrict__ weight, float clip, float vf_coef,
+                                                      float ent_coef, const float *__restrict__ inv_wsum_p, uint4 *__restrict__ dout,
+                                                      float4 *__restrict__ part) {
+    __shared__ float red[3][TK_BLOCK / 64];
+    float inv_wsum = *inv_wsum_p;
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    float s_pi = 0.f, s_v = 0.f, s_h = 0.f;
+    if (i < n) {
+        float l[64];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint4 v = out[i * 8 + q];
+            u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                l[q * 8 + 2 * k] = bf16_to_f32(wv[k] & 0xFFFFu);
+                l[q * 8 + 2 * k + 1] = bf16_to_f32(wv[k] >> 16);
+            }
+        }
+        u64 m = words[i] & TAROK_OBS_MASK;
+        float w = weight[i];
+        if (!m) { m = 1; w = 0.f; }                        // nothing to play: no contribution, finite arithmetic
+        float ws = w * inv_wsum;
+        u32 a = (u32)act[i];
+        a = a < 54 ? a : 53u;                              // (rows without a card carry weight 0)
+        float value = l[54];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < 54; c++) mx = ((m >> c) & 1) ? fmaxf(mx, l[c]) : mx;
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 54; c++) {
+            float e = ((m >> c) & 1) ? __expf(l[c] - mx) : 0.f;
+            l[c] = e;
+            sum += e;
+        }
+        float ls = __logf(sum), inv = 1.0f / sum;
+        // probabilities in place; entropy; log-prob of the played card
+        float H = 0.f, la = 0.f;
+#pragma unroll
+        for (int c = 0; c < 54; c++) {
+            float p = l[c] * inv;
+            float lp = p > 0.f ? __logf(l[c]) - ls : 0.f;  // log p_c (0 where p_c = 0: p log p -> 0)
+            H -= p * lp;
+            la = (c == (int)a) ? __logf(fmaxf(l[c], 1e-38f)) - ls : la;
+            l[c] = p;
+        }
+        float r = __expf(la - logp_old[i]);
+        float A = adv[i];
+        float rc = fminf(fmaxf(r, 1.0f - clip), 1.0f + clip);
+        float s1 = r * A, s2 = rc * A;
+        bool first = s1 <= s2;                              // which branch of the min is active
+        bool inside = r > 1.0f - clip && r < 1.0f + clip;
+        float g = (first || inside) ? -A * r : 0.f;         // d pi / d logp[a]
+        float dv = value - ret[i];
+        s_pi = w * (-fminf(s1, s2));
+        s_v = w * dv * dv;
+        s_h = w * H;
+        // d loss / d logit_c = ws [ g (delta_ca - p_c) + ent p_c (log p_c + H) ] on the legal cards
+#pragma unroll
+        for (int c = 0; c < 54; c++) {
+            float p = l[c];
+            float lp = p > 0.f ? __logf(p) : 0.f;
+            float d = g * (((c == (int)a) ? 1.0f : 0.0f) - p) + ent_coef * p * (lp + H);
+            l[c] = ((m >> c) & 1) ? ws * d : 0.f;
+        }
+        l[54] = ws * vf_coef * 2.0f * dv;
+#pragma unroll
+        for (int c = 55; c < 64; c++) l[c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint4 v;
+            u32 wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                __bf16 lo = (__bf16)l[q * 8 + 2 * k], hi = (__bf16)l[q * 8 + 2 * k + 1];
+                wv[k] = (u32)__builtin_bit_cast(unsigned short, lo) | ((u32)__builtin_bit_cast(unsigned short, hi) << 16);
+            }
+            v.x = wv[0]; v.y = wv[1]; v.z = wv[2]; v.w = wv[3];
+            dout[i * 8 + q] = v;
+        }
+    }
+    // block sums of the three loss terms (fixed order: the result does not depend on the schedule)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s_pi += __shfl_xor(s_pi, o); s_v += __shfl_xor(s_v, o); s_h += __shfl_xor(s_h, o);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_pi; red[1][threadIdx.x >> 6] = s_v; red[2][threadIdx.x >> 6] = s_h; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < TK_BLOCK / 64; k++) { a0 += red[0][k]; a1 += red[1][k]; a2 += red[2][k]; }
+        part[blockIdx.x] = make_float4(a0, a1, a2, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused policy step for a learner: observation features -> MLP 256-256-256-64
 // (bf16 MFMA, f32 accumulate) -> masked categorical sample, in ONE launch.  The features never
 // leave the chip (built in LDS from the 32-byte packed state), the activations go LDS -> MFMA ->
@@ -1241,6 +1351,20 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
                        e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
                        value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, e->stamps);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_ppo_loss(tarok_env *e, int64_t n_samples, const void *out_bf16, const uint64_t *obs, const int64_t *action,
+                   const float *logp_old, const float *advantage, const float *ret, const float *weight, float clip,
+                   float vf_coef, float ent_coef, const float *inv_weight_sum, void *dout_bf16, float *partial_out, void *stream) {
+    if (!e || n_samples <= 0 || !out_bf16 || !obs || !action || !logp_old || !advantage || !ret || !weight || !dout_bf16 ||
+        !partial_out || !inv_weight_sum)
+        return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_ppo_loss, grid_for(n_samples), dim3(TK_BLOCK), 0, (hipStream_t)stream, n_samples,
+                       (const uint4 *)out_bf16, (const u64 *)obs, action, logp_old, advantage, ret, weight, clip, vf_coef,
+                       ent_coef, inv_weight_sum, (uint4 *)dout_bf16, (float4 *)partial_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

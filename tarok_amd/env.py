@@ -287,6 +287,26 @@ class TarokVecEnv:
                                                   self._stream()))
         return action_out, logp_out, value_out
 
+    def ppo_loss(self, out, obs_words, action, logp_old, advantage, ret, weight, clip, vf_coef, ent_coef):
+        """tarok_ppo_loss: (loss terms f32 [3] = weighted means of the policy loss, the squared value
+        error and the entropy; d loss / d out [B,64] bf16) for loss = pi + vf_coef v - ent_coef H."""
+        B = out.shape[0]
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and tuple(out.shape) == (B, 64)
+        f = lambda t: t.to(torch.float32).contiguous()
+        logp_old, advantage, ret, weight = f(logp_old), f(advantage), f(ret), f(weight)
+        action = action.to(torch.int64).contiguous()
+        obs_words = obs_words.to(torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            inv = (1.0 / weight.sum().clamp(min=1.0)).reshape(1).contiguous()
+            dout = torch.empty_like(out)
+            part = torch.empty(((B + 255) // 256, 4), dtype=torch.float32, device=self.device)
+            _native.check(self.L.tarok_ppo_loss(self._h, int(B), self._p(out), self._p(obs_words), self._p(action),
+                                                self._p(logp_old), self._p(advantage), self._p(ret), self._p(weight),
+                                                float(clip), float(vf_coef), float(ent_coef), self._p(inv), self._p(dout),
+                                                self._p(part), self._stream()))
+            terms = part.sum(0)[:3] * inv
+        return terms, dout
+
     @staticmethod
     def expand_feature_words(words, dtype=torch.bfloat16):
         """[..., 4] int64 feature words (tarok_policy_mlp feature_words_out) -> [..., 256] 0/1 features."""

@@ -148,7 +148,7 @@ class SelfPlay:
     hidden size the policy runs as tarok_observe -> torch GEMMs -> tarok_sample_policy."""
 
     def __init__(self, env, hidden=256, lr=3e-4, clip=0.2, vf_coef=0.5, ent_coef=0.01, reward_scale=1.0 / 70.0, seed=0,
-                 use_graph=True, fused=None):
+                 use_graph=True, fused=None, fused_loss=None):
         self.env = env
         self.device = env.device
         torch.manual_seed(seed)                       # same initial weights on every rank
@@ -161,6 +161,8 @@ class SelfPlay:
         self.use_graph = use_graph
         self.fused = (hidden == 256) if fused is None else bool(fused)
         assert not self.fused or hidden == 256, "tarok_policy_mlp is built for hidden = 256"
+        # the loss and its gradient in one kernel (tarok_ppo_loss) instead of ~40 framework kernels
+        self.fused_loss = True if fused_loss is None else bool(fused_loss)
         self._graph, self._buf, self._T = None, None, 0
         self._w = None                                # rollout copies of the weights (bf16) / biases (f32)
 
@@ -256,39 +258,48 @@ class SelfPlay:
         std = (((adv - mean) ** 2 * m).sum() / m.sum().clamp(min=1)).sqrt().clamp(min=1e-6)
         adv = (adv - mean) / std
         stats = dict(loss=0.0, pi_loss=0.0, v_loss=0.0, entropy=0.0, allreduce_bytes=0, known_frac=float(m.mean()))
+        sums = torch.zeros(4, dtype=torch.float32, device=self.device)     # loss terms summed on the device: no host sync per minibatch
         params = [p for p in self.net.parameters()]
         count = 0
         for _ in range(epochs):
             perm = torch.randperm(T * n, device=self.device, generator=self.gen)
             for idx in perm.chunk(minibatches):
                 x = self.env.expand_feature_words(obs[idx]) if self.fused else obs[idx]
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    logits, val = self.net(x)
-                legal = legal_matrix(words[idx] & K.OBS_MASK)
-                lg = logits.float().masked_fill(~legal, float("-inf"))
-                logp_all = F.log_softmax(lg, dim=-1)
-                logp = logp_all.gather(-1, act[idx].clamp(max=53).unsqueeze(-1)).squeeze(-1)
                 w = m[idx]
-                wsum = w.sum().clamp(min=1)
-                ratio = (logp - logp0[idx]).exp()
                 a = adv[idx]
-                pi_loss = -(torch.min(ratio * a, ratio.clamp(1 - self.clip, 1 + self.clip) * a) * w).sum() / wsum
-                v_loss = (((val.float() - ret[idx]) ** 2) * w).sum() / wsum
-                p = logp_all.exp()
-                ent = (-(p * torch.where(legal, logp_all, torch.zeros_like(logp_all))).sum(-1) * w).sum() / wsum
-                loss = pi_loss + self.vf_coef * v_loss - self.ent_coef * ent
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
+                if self.fused_loss:
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        out = self.net.forward_raw(x)
+                    out = out.to(torch.bfloat16).contiguous()
+                    terms, dout = self.env.ppo_loss(out.detach(), words[idx], act[idx], logp0[idx], a, ret[idx], w,
+                                                    self.clip, self.vf_coef, self.ent_coef)
+                    pi_loss, v_loss, ent = terms[0], terms[1], terms[2]
+                    loss = pi_loss + self.vf_coef * v_loss - self.ent_coef * ent
+                    self.opt.zero_grad(set_to_none=True)
+                    out.backward(dout)
+                else:
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        logits, val = self.net(x)
+                    legal = legal_matrix(words[idx] & K.OBS_MASK)
+                    lg = logits.float().masked_fill(~legal, float("-inf"))
+                    logp_all = F.log_softmax(lg, dim=-1)
+                    logp = logp_all.gather(-1, act[idx].clamp(max=53).unsqueeze(-1)).squeeze(-1)
+                    wsum = w.sum().clamp(min=1)
+                    ratio = (logp - logp0[idx]).exp()
+                    pi_loss = -(torch.min(ratio * a, ratio.clamp(1 - self.clip, 1 + self.clip) * a) * w).sum() / wsum
+                    v_loss = (((val.float() - ret[idx]) ** 2) * w).sum() / wsum
+                    p = logp_all.exp()
+                    ent = (-(p * torch.where(legal, logp_all, torch.zeros_like(logp_all))).sum(-1) * w).sum() / wsum
+                    loss = pi_loss + self.vf_coef * v_loss - self.ent_coef * ent
+                    self.opt.zero_grad(set_to_none=True)
+                    loss.backward()
                 stats["allreduce_bytes"] = allreduce_gradients(params)
                 nn.utils.clip_grad_norm_(params, 1.0)
                 self.opt.step()
                 count += 1
-                stats["loss"] += float(loss.detach())
-                stats["pi_loss"] += float(pi_loss.detach())
-                stats["v_loss"] += float(v_loss.detach())
-                stats["entropy"] += float(ent.detach())
-        for k in ("loss", "pi_loss", "v_loss", "entropy"):
-            stats[k] /= max(1, count)
+                sums += torch.stack([loss.detach().float(), pi_loss.detach().float(), v_loss.detach().float(), ent.detach().float()])
+        for k, v in zip(("loss", "pi_loss", "v_loss", "entropy"), sums.tolist()):
+            stats[k] = v / max(1, count)
         return stats
 
     def iterate(self, T=48, epochs=2, minibatches=8):

@@ -493,6 +493,51 @@ def test_selfplay_iteration_runs_and_learns_something_finite(T, S):
     env.close()
 
 
+def test_ppo_loss_kernel_vs_torch(T, S):
+    """tarok_ppo_loss (clipped surrogate + value loss - entropy over the legal cards, forward and
+    gradient in one pass) vs the same loss written with torch ops and differentiated by autograd."""
+    import torch
+    import torch.nn.functional as F
+    from tarok_amd import selfplay as SP
+    n = 20000                                         # not a multiple of 256
+    env = T.TarokVecEnv(n, seed=3, mix=S.MIX_ALL)
+    obs = env.reset()
+    for t in range(5):
+        obs, _, _ = env.step(env.policy_random(obs), auto_reset=True)
+    words = obs.words.clone()
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    out = (torch.randn((n, 64), device="cuda", generator=g) * 2).to(torch.bfloat16)
+    legal = SP.legal_matrix(words & T.karte.OBS_MASK)
+    act = torch.multinomial(legal.float(), 1, generator=g).squeeze(1)
+    with torch.no_grad():
+        lp_now = F.log_softmax(out[:, :54].float().masked_fill(~legal, float("-inf")), -1).gather(1, act[:, None]).squeeze(1)
+    logp_old = lp_now + 0.4 * torch.randn(n, device="cuda", generator=g)            # ratios on both sides of the clip range
+    adv = torch.randn(n, device="cuda", generator=g)
+    ret = torch.randn(n, device="cuda", generator=g)
+    w = (torch.rand(n, device="cuda", generator=g) < 0.8).float()
+    clip, vf, ent_c = 0.2, 0.5, 0.01
+    terms, dout = env.ppo_loss(out, words, act, logp_old, adv, ret, w, clip, vf, ent_c)
+    x = out.float().requires_grad_(True)
+    lg = x[:, :54].masked_fill(~legal, float("-inf"))
+    logp_all = F.log_softmax(lg, dim=-1)
+    logp = logp_all.gather(-1, act[:, None]).squeeze(-1)
+    wsum = w.sum().clamp(min=1)
+    ratio = (logp - logp_old).exp()
+    pi = -(torch.min(ratio * adv, ratio.clamp(1 - clip, 1 + clip) * adv) * w).sum() / wsum
+    v = (((x[:, 54] - ret) ** 2) * w).sum() / wsum
+    p = logp_all.exp()
+    H = (-(p * torch.where(legal, logp_all, torch.zeros_like(logp_all))).sum(-1) * w).sum() / wsum
+    (pi + vf * v - ent_c * H).backward()
+    ref = torch.stack([pi, v, H]).detach()
+    assert torch.allclose(terms, ref, rtol=2e-3, atol=2e-4), (terms, ref)
+    gref = x.grad
+    err = (dout.float() - gref).abs()
+    scale = gref.abs().max().item()
+    assert err.max().item() < 0.01 * scale + 1e-9, (err.max().item(), scale)          # bf16 rounding of the output
+    assert (dout[:, 55:] == 0).all().item() and (dout[:, :54][~legal] == 0).all().item()
+    env.close()
+
+
 def test_sample_policy_kernel(T, S):
     """tarok_sample_policy: always a legal card; log-prob equals torch's masked log-softmax;
     draws follow the softmax (pooled chi-square-style check on identical rows)."""
