@@ -49,12 +49,12 @@ class _LinearSplitK(torch.autograd.Function):
         gy = gy.contiguous()
         gx = (gy @ wq).to(dx) if ctx.needs_input_grad[0] else None
         B = xq.shape[0]
-        S = next((s for s in (128, 96, 64, 48, 32, 24, 16, 8, 4, 2) if B % s == 0 and B // s >= 512), 1)
+        S = next((s for s in (32, 24, 16, 12, 8, 4, 2) if B % s == 0 and B // s >= 512), 1)      # S x 16 tiles >= 256 CUs
         if S > 1:
-            gw = torch.bmm(gy.view(S, B // S, -1).transpose(1, 2), xq.view(S, B // S, -1)).float().sum(0)
+            gw = torch.bmm(gy.view(S, B // S, -1).transpose(1, 2), xq.view(S, B // S, -1)).sum(0, dtype=torch.float32)
         else:
             gw = (gy.t() @ xq).float()
-        return gx, gw.to(dw), gy.float().sum(0).to(db)
+        return gx, gw.to(dw), gy.sum(0, dtype=torch.float32).to(db)
 
 
 class PolicyNet(nn.Module):

@@ -89,3 +89,28 @@ def test_gradient_allreduce_two_ranks_gloo():
     for g0, g1, r0, r1 in zip(l0, l1, a0, a1):
         np.testing.assert_allclose(r0, (g0 + g1) / 2, rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(r0, r1)
+
+
+def test_split_k_linear_gives_the_plain_gradients():
+    """_LinearSplitK (weight gradient as a batch of partial products) vs nn.Linear on the same
+    minibatch: outputs and all gradients agree (f32 on the CPU: to rounding of the summation order)."""
+    import torch
+    from tarok_amd import selfplay as SP
+    torch.manual_seed(0)
+    net = SP.PolicyNet(256)
+    x = torch.randn(16384 * 2, 256)
+
+    def run(split):
+        net.zero_grad()
+        if split:
+            out = net.forward_raw(x)                          # >= 16384 rows with grad enabled: the split-K path
+        else:
+            h = torch.relu(net.fc1(x)); h = torch.relu(net.fc2(h)); out = net.head(h)
+        (out ** 2).mean().backward()
+        return [p.grad.clone() for p in net.parameters()], out.detach()
+
+    g1, o1 = run(True)
+    g0, o0 = run(False)
+    assert torch.equal(o1, o0)
+    for a, b in zip(g1, g0):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-7)
