@@ -847,20 +847,35 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     }
     __syncthreads();
     PM_STAMP(6)
-    // expand to bf16 0.0 / 1.0: per iteration 8 games, 32 lanes per game, one 16-byte chunk (8
-    // features = one byte of a feature word) per lane: the optional global copy leaves as full rows
-    // (a 256-entry LDS table byte -> 8 bf16 was tried: no faster than the selects)
+    // expand to bf16 0.0 / 1.0, one 16-byte chunk (8 features = one byte of a feature word) at a time.
+    // Two threads per game, thread parity p takes the odd / even bytes of the game's 32: ONE 32-byte
+    // LDS read per thread up front instead of a dependent byte read per chunk, and the pair's
+    // 16-byte stores fall into different banks.  (A 256-entry LDS table byte -> 8 bf16 was tried:
+    // no faster than the selects.)
+    {
+        u32 gme = tid >> 1, par = tid & 1;
+        const uint4 *row = reinterpret_cast<const uint4 *>(&ext[gme][0]);
+        uint4 r0 = row[0], r1 = row[1];
+        u32 wd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-    for (int it = 0; it < PM_M / 8; it++) {
-        u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
-        u32 byte = reinterpret_cast<const uint8_t *>(&ext[gme][0])[chunk];
-        uint4 v;
-        v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
-        v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
-        v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
-        v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
-        *reinterpret_cast<uint4 *>(X + gme * PM_LD + 8 * chunk) = v;
-        if (features_out && base + gme < n) features_out[(base + gme) * 32 + chunk] = v;
+        for (int j = 0; j < 16; j++) {
+            u32 chunk = 2 * j + par;                       // byte `chunk` of the row = byte (2j + par) & 3 of word j / 2
+            u32 byte = (wd[j >> 1] >> (8 * ((2 * (j & 1)) + par))) & 255u;
+            uint4 v;
+            v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
+            v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
+            v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
+            v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+            *reinterpret_cast<uint4 *>(X + gme * PM_LD + 8 * chunk) = v;
+        }
+    }
+    if (features_out) {                                    // optional global copy: full 512-byte rows per 32 lanes
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < PM_M / 8; it++) {
+            u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
+            if (base + gme < n) features_out[(base + gme) * 32 + chunk] = *reinterpret_cast<const uint4 *>(X + gme * PM_LD + 8 * chunk);
+        }
     }
     __syncthreads();
     PM_STAMP(1)

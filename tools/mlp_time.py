@@ -41,7 +41,7 @@ from tarok_amd import _native
 nb = (n + 127) // 128
 st = torch.zeros((max(nb * 8, (n + 63) // 64 * 3), ), dtype=torch.int64, device="cuda")
 _native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
-env.policy_mlp(w, words, a, lp, v, features_out=feat)
+env.policy_mlp(w, words, a, lp, v)
 torch.cuda.synchronize()
 _native.check(env.L.tarok_debug_stamps(env._h, None))
 t = st[: nb * 8].view(nb, 8).cpu().numpy()
