@@ -256,8 +256,9 @@ def main():
             out["selfplay_ppo"] = {"rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_ms_per_step": tro[0] / 48 * 1e3,
                                    "update_ms": tro[1] * 1e3, "minibatches": 8, "allreduce_bytes_per_minibatch": st["allreduce_bytes"],
                                    "policy": "MLP 256-256-256-64 (54 card logits + value), bf16 MFMA", "loss": st["loss"],
-                                   "note": "env steps/s including the policy: per lock-step one tarok_policy_mlp launch "
-                                           "(features -> MLP -> masked sample, fused) + one tarok_step launch, graph replayed"}
+                                   "note": "env steps/s including the policy: per lock-step one tarok_policy_step launch "
+                                           "(features -> MLP -> masked sample -> env step), graph replayed; update = PPO-style, "
+                                           "tarok_ppo_loss + torch GEMMs"}
             del sp
         except Exception as ex:                      # never let the side leg break the bench line
             out["selfplay_ppo"] = {"error": repr(ex)}

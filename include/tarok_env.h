@@ -223,6 +223,15 @@ int tarok_policy_mlp(tarok_env *env, const void *w1, const float *b1, const void
                      float *logp_out, float *value_out, void *features_out, uint64_t *feature_words_out,
                      void *stream);
 
+/* tarok_policy_mlp followed by tarok_step(action_out, ...) in ONE launch: the workgroup that
+ * evaluated the policy for 256 games plays the sampled cards at once (same results as the two
+ * calls; saves a launch and its gap per lock-step).  Arguments as in those two functions; obs is
+ * the observation BEFORE the step (legal masks), obs_out the one after it (they may not alias). */
+int tarok_policy_step(tarok_env *env, const void *w1, const float *b1, const void *w2, const float *b2,
+                      const void *w3, const float *b3, const uint64_t *obs, uint8_t *action_out,
+                      float *logp_out, float *value_out, uint64_t *feature_words_out, int16_t *reward_out,
+                      uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
+
 /* The learner's loss for the policy above, forward and gradient in one pass: clipped-surrogate
  * policy loss + value loss - entropy bonus over the LEGAL cards of every sample (build-owned:
  * the reference has no policy-gradient learner).

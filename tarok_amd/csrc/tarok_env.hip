@@ -270,51 +270,58 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
 //
 // Workgroups [0, play_groups) play; the workgroups after them work off the refill lists the
 // PREVIOUS launch wrote (see the file header).
+// Refill role of a step launch: work off the lists the PREVIOUS launch wrote for `fan` play
+// workgroups (rblock = index among the refill workgroups; tid / nthreads = this thread in its
+// workgroup), concatenated so that the sorting-network deals run on dense lanes (~11 % of the
+// slots of a group finish per trick: 8 lists fill a 256-thread workgroup).  Small batches use a
+// smaller fan: a refill workgroup that needs a second pass would outlast the play.
+__device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
+                                        u32 par, u32 fan, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
+                                        const u32 *__restrict__ rcount) {
+    u32 g0 = rblock * fan;
+    u32 cum[TK_REFILL_FAN + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (u32 q = 0; q < TK_REFILL_FAN; q++)
+        cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[TK_RC(g0 + q, par ^ 1)] : 0u);
+    for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
+        u32 q = 0;
+#pragma unroll
+        for (u32 r = 1; r < TK_REFILL_FAN; r++) q += j >= cum[r] ? 1u : 0u;
+        u32 base = 0;
+#pragma unroll
+        for (u32 r = 0; r < TK_REFILL_FAN; r++) base = (r == q) ? cum[r] : base;
+        u64 en = rlist[((int64_t)(g0 + q) * 2 + (par ^ 1)) * TK_REFILL_CAP + (j - base)];
+        deal_into_buffer(aux, (int64_t)(g0 + q) * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
+    }
+}
+
+// Play role of a step launch for the 256 slots of play workgroup `group`: thread `tid` (0..255)
+// plays slot group * 256 + tid; threads with active = false (a larger workgroup's extra threads)
+// only take part in the two barriers.  The card comes from action_in, or (action_in == NULL) from
+// a_reg, or with RANDOM from the in-kernel Bot policy.
 template <bool RANDOM>
-__global__ __launch_bounds__(TK_BLOCK) void k_play(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
+__device__ __forceinline__ void play_role(
+    u32 group, u32 tid, bool active, u32 a_reg,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 par,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
-    if (blockIdx.x >= play_groups) {
-        // ---- refill role: the lists the previous launch wrote for `fan` play workgroups,
-        // concatenated so that the sorting-network deals run on dense lanes (~11 % of the slots
-        // of a group finish per trick: 8 lists fill a 256-thread workgroup).  Small batches use a
-        // smaller fan: a refill workgroup that needs a second pass would outlast the play.
-        u32 g0 = (blockIdx.x - play_groups) * fan;
-        u32 cum[TK_REFILL_FAN + 1];
-        cum[0] = 0;
-#pragma unroll
-        for (u32 q = 0; q < TK_REFILL_FAN; q++)
-            cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[TK_RC(g0 + q, par ^ 1)] : 0u);
-        for (u32 j = threadIdx.x; j < cum[TK_REFILL_FAN]; j += TK_BLOCK) {
-            u32 q = 0;
-#pragma unroll
-            for (u32 r = 1; r < TK_REFILL_FAN; r++) q += j >= cum[r] ? 1u : 0u;
-            u32 base = 0;
-#pragma unroll
-            for (u32 r = 0; r < TK_REFILL_FAN; r++) base = (r == q) ? cum[r] : base;
-            u64 en = rlist[((int64_t)(g0 + q) * 2 + (par ^ 1)) * TK_REFILL_CAP + (j - base)];
-            deal_into_buffer(aux, (int64_t)(g0 + q) * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
-        }
-        return;
-    }
-    // ---- play role
     __shared__ u64 push_list[TK_REFILL_CAP];
     __shared__ u32 push_count;
-    if (threadIdx.x == 0) push_count = 0;
+    if (tid == 0) push_count = 0;
     __syncthreads();
     u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
     if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
-    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
-    bool valid = i < n;
+    int64_t i = (int64_t)group * TK_BLOCK + tid;
+    bool valid = active && i < n;
     int64_t ic = valid ? i : n - 1;
     Game g;
     load_game(g, s01, s23, ic);
     u64 key = 0;
     u32 a_in = 255;
-    if (RANDOM) key = gkey[ic]; else a_in = action_in[ic];
+    if (RANDOM) key = gkey[ic]; else a_in = action_in ? action_in[ic] : a_reg;
     bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
     // Lanes that can reach the end of their game within this launch (a game only ends on the 4th
     // card of a trick: Berac on any trick, the others in trick 12) issue their finish-path loads
@@ -446,19 +453,35 @@ __global__ __launch_bounds__(TK_BLOCK) void k_play(
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
     if (valid && np) {
         u32 pos = atomicAdd(&push_count, np);
-        for (u32 j = 0; j < np; j++) push_list[pos + j] = ((u64)(cur_ep + TK_AHEAD - j) << 32) | threadIdx.x;
+        for (u32 j = 0; j < np; j++) push_list[pos + j] = ((u64)(cur_ep + TK_AHEAD - j) << 32) | tid;
     }
     __syncthreads();
     u32 total = push_count;
-    u64 *lst = rlist + ((int64_t)blockIdx.x * 2 + par) * TK_REFILL_CAP;
-    for (u32 j = threadIdx.x; j < total; j += TK_BLOCK) lst[j] = push_list[j];
-    if (threadIdx.x == 0) rcount[TK_RC(blockIdx.x, par)] = total;
-    if (stamps && (threadIdx.x & 63) == 0) {     // diagnostics only
+    u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
+    if (active)
+        for (u32 j = tid; j < total; j += TK_BLOCK) lst[j] = push_list[j];
+    if (tid == 0) rcount[TK_RC(group, par)] = total;
+    if (stamps && active && (tid & 63) == 0) {     // diagnostics only
         u64 w = (u64)i >> 6;
         stamps[3 * w + 0] = t_real0;
         stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
     }
+}
+
+template <bool RANDOM>
+__global__ __launch_bounds__(TK_BLOCK) void k_play(
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
+    const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
+    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
+    if (blockIdx.x >= play_groups) {
+        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
+        return;
+    }
+    play_role<RANDOM>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in, action_out,
+                      reward, done, trick, obs, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -754,9 +777,10 @@ __device__ __forceinline__ void mlp_prefetch(bf16x8 (&wq)[4][2], const __bf16 *_
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// (X: the 128-game tile of this wave; wave = 0..3 within the tile; the barriers are workgroup-wide)
 __device__ __forceinline__ void mlp_hidden(__bf16 *__restrict__ X, const __bf16 *__restrict__ w, const float *__restrict__ bias,
-                                           bf16x8 (&wq)[4][2]) {
-    u32 lane = __lane_id(), wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+                                           bf16x8 (&wq)[4][2], u32 wave) {
+    u32 lane = __lane_id(), r = lane & 31, h = lane >> 5;
     const bf16x8 *wf = reinterpret_cast<const bf16x8 *>(w) + (size_t)(wave * 2) * 16 * 64 + lane;
     f32x16 acc[2][4];
 #pragma unroll
@@ -809,23 +833,30 @@ __device__ __forceinline__ void mlp_hidden(__bf16 *__restrict__ X, const __bf16 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
+// The policy step of 128 * TILES games by a workgroup of 256 * TILES threads (tile t = waves
+// 4t..4t+3 and rows 128t.. of X).  TILES = 1: tarok_policy_mlp; TILES = 2: the first half of
+// tarok_policy_step, which then needs the sampled cards of its 256 games in LDS (act_s).
+template <int TILES>
+__device__ __forceinline__ void policy_body(
     int64_t n, const ulonglong2 *__restrict__ s01, const ulonglong2 *__restrict__ s23, const u64 *__restrict__ obs,
     const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
-    uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps) {
+    uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps,
+    uint8_t *__restrict__ act_s) {
+    constexpr int GAMES = PM_M * TILES;
     u64 ts[7];
 #define PM_STAMP(k) if (stamps) ts[k] = __builtin_amdgcn_s_memtime();
     PM_STAMP(0)
-    __shared__ __attribute__((aligned(16))) __bf16 X[PM_M * PM_LD];
-    __shared__ u64 ext[PM_M][4];
-    int64_t base = (int64_t)blockIdx.x * PM_M;
-    u32 tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) __bf16 X[GAMES * PM_LD];
+    __shared__ u64 ext[GAMES][4];
+    int64_t base = (int64_t)blockIdx.x * GAMES;
+    u32 tid = threadIdx.x, wave4 = (tid >> 6) & 3, tile = tid >> 8;
+    __bf16 *Xt = X + tile * PM_M * PM_LD;
     bf16x8 wq[4][2];
-    mlp_prefetch(wq, w1, (tid >> 6) * 2);           // lands while the features are built
+    mlp_prefetch(wq, w1, wave4 * 2);           // lands while the features are built
     // ---- the four 64-bit feature words of each game (same definition as k_observe)
-    if (tid < PM_M) {
+    if (tid < GAMES) {
         int64_t i = base + tid < n ? base + tid : n - 1;
         Game g;
         load_game(g, s01, s23, i);
@@ -872,23 +903,23 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
     if (features_out) {                                    // optional global copy: full 512-byte rows per 32 lanes
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < PM_M / 8; it++) {
-            u32 gme = it * 8 + (tid >> 5), chunk = tid & 31;
+        for (int it = 0; it < 16; it++) {
+            u32 gme = it * (8 * TILES) + (tid >> 5), chunk = tid & 31;
             if (base + gme < n) features_out[(base + gme) * 32 + chunk] = *reinterpret_cast<const uint4 *>(X + gme * PM_LD + 8 * chunk);
         }
     }
     __syncthreads();
     PM_STAMP(1)
-    mlp_hidden(X, w1, b1, wq);
+    mlp_hidden(Xt, w1, b1, wq, wave4);
     PM_STAMP(2)
-    mlp_prefetch(wq, w2, (tid >> 6) * 2);
-    mlp_hidden(X, w2, b2, wq);
+    mlp_prefetch(wq, w2, wave4 * 2);
+    mlp_hidden(Xt, w2, b2, wq, wave4);
     PM_STAMP(3)
     // ---- layer 3: 64 outputs; wave w takes games [32w, 32w+32), both 32-feature tiles; f32
     // logits to LDS [128][68] over the activation buffer
     float *L = reinterpret_cast<float *>(X);
     {
-        u32 lane = __lane_id(), wave = tid >> 6, r = lane & 31, h = lane >> 5;
+        u32 lane = __lane_id(), wave = wave4, r = lane & 31, h = lane >> 5;
         const bf16x8 *wf = reinterpret_cast<const bf16x8 *>(w3) + lane;
         f32x16 acc[2];
 #pragma unroll
@@ -900,7 +931,7 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
         for (int d = 0; d < 4; d++)
 #pragma unroll
             for (int ft = 0; ft < 2; ft++) wq[d][ft] = wf[(ft * 16 + d) * 64];
-        bf16x8 xn = *reinterpret_cast<const bf16x8 *>(X + (32 * wave + r) * PM_LD + 8 * h);
+        bf16x8 xn = *reinterpret_cast<const bf16x8 *>(Xt + (32 * wave + r) * PM_LD + 8 * h);
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             bf16x8 x = xn;
@@ -909,7 +940,7 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
 #pragma unroll
                 for (int ft = 0; ft < 2; ft++) wq[kk & 3][ft] = wf[(ft * 16 + kk + 4) * 64];
             }
-            if (kk < 15) xn = *reinterpret_cast<const bf16x8 *>(X + (32 * wave + r) * PM_LD + 16 * (kk + 1) + 8 * h);
+            if (kk < 15) xn = *reinterpret_cast<const bf16x8 *>(Xt + (32 * wave + r) * PM_LD + 16 * (kk + 1) + 8 * h);
 #pragma unroll
             for (int ft = 0; ft < 2; ft++) acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[ft], x, acc[ft], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -922,7 +953,7 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
                 u32 f0 = 32 * ft + 8 * q + 4 * h;
                 float4 bv = *reinterpret_cast<const float4 *>(b3 + f0);
                 float4 o = make_float4(acc[ft][4 * q + 0] + bv.x, acc[ft][4 * q + 1] + bv.y, acc[ft][4 * q + 2] + bv.z, acc[ft][4 * q + 3] + bv.w);
-                *reinterpret_cast<float4 *>(L + (32 * wave + r) * PM_LL + f0) = o;
+                *reinterpret_cast<float4 *>(L + (PM_M * tile + 32 * wave + r) * PM_LL + f0) = o;
             }
     }
     __syncthreads();
@@ -992,11 +1023,49 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
                 action[i] = (uint8_t)pk;
                 if (logp) logp[i] = __logf(pp / sum);
             }
+            if (act_s) act_s[gi] = m ? (uint8_t)pk : (uint8_t)255;
         }
 #undef PM_SWAP_F
 #undef PM_SWAP_I
         if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
     }
+}
+
+__global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
+    int64_t n, const ulonglong2 *__restrict__ s01, const ulonglong2 *__restrict__ s23, const u64 *__restrict__ obs,
+    const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
+    const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
+    const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
+    uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps) {
+    policy_body<1>(n, s01, s23, obs, gkey, w1, b1, w2, b2, w3, b3, action, logp, value, features_out, feature_words_out, stamps,
+                   nullptr);
+}
+
+// tarok_policy_step: tarok_policy_mlp and tarok_step in ONE launch.  A play workgroup (512
+// threads, 256 games = the 256 slots of step group blockIdx.x) evaluates the policy for its games
+// as two 128-game tiles side by side, leaves the sampled cards in LDS and then runs the step
+// kernel's play role on them (threads 0..255; same refill lists, same launch-parity protocol as
+// k_play); the workgroups after the play groups run the refill role.
+__global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 par, u32 fan,
+    const u64 *__restrict__ obs_in, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
+    const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
+    const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
+    ulonglong2 *__restrict__ feature_words_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
+    uint16_t *__restrict__ trick, u64 *__restrict__ obs_out,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
+    if (blockIdx.x >= play_groups) {
+        refill_role(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
+        return;
+    }
+    __shared__ uint8_t act_s[2 * PM_M];
+    policy_body<2>(n, s01, s23, obs_in, gkey, w1, b1, w2, b2, w3, b3, action, logp, value, nullptr, feature_words_out, nullptr,
+                   act_s);
+    __syncthreads();
+    u32 tid = threadIdx.x;
+    play_role<false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n, par,
+                     nullptr, nullptr, reward, done, trick, obs_out, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
 }
 
 __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
@@ -1366,6 +1435,25 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
                        e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
                        value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, e->stamps);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void *w2, const float *b2, const void *w3,
+                      const float *b3, const uint64_t *obs, uint8_t *action_out, float *logp_out, float *value_out,
+                      uint64_t *feature_words_out, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
+                      uint64_t *obs_out, int flags, void *stream) {
+    if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out || !obs_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
+    u32 par = e->launch_no & 1u;
+    e->launch_no++;
+    u32 fan = e->refill_fan;
+    dim3 grid(groups + (groups + fan - 1) / fan);
+    hipLaunchKernelGGL(k_policy_step, grid, dim3(2 * TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset, e->mix, flags,
+                       groups, par, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
+                       action_out, logp_out, value_out, (ulonglong2 *)feature_words_out, reward_out, done_out, trick_out,
+                       (u64 *)obs_out, e->s01, e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

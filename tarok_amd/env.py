@@ -287,6 +287,19 @@ class TarokVecEnv:
                                                   self._stream()))
         return action_out, logp_out, value_out
 
+    def policy_step(self, weights, obs_words, obs_out, action_out, logp_out=None, value_out=None, feature_words_out=None,
+                    reward_out=None, done_out=None, auto_reset=True):
+        """policy_mlp + step in one launch (tarok_policy_step): samples a card per game from the MLP
+        policy on `obs_words` and plays it; obs_out receives the next observation words."""
+        w1, b1, w2, b2, w3, b3 = weights
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_policy_step(self._h, self._p(w1), self._p(b1), self._p(w2), self._p(b2), self._p(w3),
+                                                   self._p(b3), self._p(obs_words), self._p(action_out), self._p(logp_out),
+                                                   self._p(value_out), self._p(feature_words_out), self._p(reward_out),
+                                                   self._p(done_out), None, self._p(obs_out),
+                                                   K.AUTO_RESET if auto_reset else 0, self._stream()))
+        return action_out
+
     def ppo_loss(self, out, obs_words, action, logp_old, advantage, ret, weight, clip, vf_coef, ent_coef):
         """tarok_ppo_loss: (loss terms f32 [3] = weighted means of the policy loss, the squared value
         error and the entropy; d loss / d out [B,64] bf16) for loss = pi + vf_coef v - ent_coef H."""

@@ -148,7 +148,7 @@ class SelfPlay:
     hidden size the policy runs as tarok_observe -> torch GEMMs -> tarok_sample_policy."""
 
     def __init__(self, env, hidden=256, lr=3e-4, clip=0.2, vf_coef=0.5, ent_coef=0.01, reward_scale=1.0 / 70.0, seed=0,
-                 use_graph=True, fused=None, fused_loss=None):
+                 use_graph=True, fused=None, fused_loss=None, fused_step=None):
         self.env = env
         self.device = env.device
         torch.manual_seed(seed)                       # same initial weights on every rank
@@ -163,6 +163,8 @@ class SelfPlay:
         assert not self.fused or hidden == 256, "tarok_policy_mlp is built for hidden = 256"
         # the loss and its gradient in one kernel (tarok_ppo_loss) instead of ~40 framework kernels
         self.fused_loss = True if fused_loss is None else bool(fused_loss)
+        # policy and env step in one launch per lock-step (tarok_policy_step)
+        self.fused_step = self.fused if fused_step is None else bool(fused_step)
         self._graph, self._buf, self._T = None, None, 0
         self._w = None                                # rollout copies of the weights (bf16) / biases (f32)
 
@@ -198,6 +200,10 @@ class SelfPlay:
     def _rollout_body(self, T):
         env, buf, w = self.env, self._buf, self._w
         for t in range(T):
+            if self.fused and self.fused_step:
+                env.policy_step(w, buf["words"][t], buf["words"][t + 1], buf["act"][t], buf["logp"][t], buf["val"][t],
+                                feature_words_out=buf["obs"][t], reward_out=buf["reward"][t], done_out=buf["done"][t])
+                continue
             if self.fused:
                 env.policy_mlp(w, buf["words"][t], buf["act"][t], buf["logp"][t], buf["val"][t], feature_words_out=buf["obs"][t])
             else:

@@ -493,6 +493,35 @@ def test_selfplay_iteration_runs_and_learns_something_finite(T, S):
     env.close()
 
 
+def test_policy_step_kernel_equals_policy_then_step(T, S):
+    """tarok_policy_step (policy MLP + sampling + env step in one launch) vs tarok_policy_mlp followed
+    by tarok_step: every rollout buffer, the counters and the final env state are identical; the
+    ragged last workgroup and games finishing (auto-reset, refill lists) included."""
+    import torch
+    from tarok_amd import selfplay as SP
+    n = 20000 + 77
+    res = []
+    for fused_step in (False, True):
+        env = T.TarokVecEnv(n, seed=41, mix=S.MIX_ALL, game_offset=5)
+        sp = SP.SelfPlay(env, hidden=256, seed=0, fused_step=fused_step)
+        for it in range(2):                               # the second collect replays the captured graph
+            b = sp.collect(40)
+        torch.cuda.synchronize()
+        ep, ss = env.counters()
+        res.append(({k: v.clone() for k, v in b.items()}, ep.copy(), ss.copy(), env.state().copy()))
+        del sp
+        env.close()
+    (b0, ep0, ss0, st0), (b1, ep1, ss1, st1) = res
+    for k in b0:
+        if k == "reward":
+            d = b0["done"].bool()
+            assert (b0[k][d] == b1[k][d]).all().item(), k
+        else:
+            assert (b0[k] == b1[k]).all().item(), k
+    assert (ep0 == ep1).all() and (ss0 == ss1).all() and (st0 == st1).all()
+    assert ep0.sum() > n                                  # games did finish and were replaced
+
+
 def test_ppo_loss_kernel_vs_torch(T, S):
     """tarok_ppo_loss (clipped surrogate + value loss - entropy over the legal cards, forward and
     gradient in one pass) vs the same loss written with torch ops and differentiated by autograd."""

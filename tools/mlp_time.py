@@ -29,6 +29,14 @@ def bench(fn, reps=20, per=10):
     return (time.perf_counter() - t0) / (reps * per) * 1e6
 print("policy_mlp with features_out: %.1f us" % bench(lambda: env.policy_mlp(w, words, a, lp, v, features_out=feat)))
 print("policy_mlp no features_out:   %.1f us" % bench(lambda: env.policy_mlp(w, words, a, lp, v)))
+fw = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+w2 = torch.empty(n, dtype=torch.int64, device="cuda"); rw = torch.zeros((n, 4), dtype=torch.int16, device="cuda"); dn = torch.zeros(n, dtype=torch.uint8, device="cuda")
+print("policy_mlp + feature words:   %.1f us" % bench(lambda: env.policy_mlp(w, words, a, lp, v, feature_words_out=fw)))
+def two():
+    env.policy_mlp(w, words, a, lp, v, feature_words_out=fw)
+    env.step(a, auto_reset=True, obs_out=w2, reward_out=rw, done_out=dn)
+print("policy_mlp then step:         %.1f us" % bench(two))
+print("policy_step (one launch):     %.1f us" % bench(lambda: env.policy_step(w, words, w2, a, lp, v, feature_words_out=fw, reward_out=rw, done_out=dn)))
 print("observe:                      %.1f us" % bench(lambda: env.observe(feat)))
 lg = torch.randn((n, 64), device="cuda").to(torch.bfloat16)
 print("sample_policy:                %.1f us" % bench(lambda: env.sample_policy(lg, words, a, lp)))
