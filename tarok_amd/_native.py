@@ -41,14 +41,31 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> tarok_amd/libtarokenv.so (in-tree)."""
+    """hipcc --offload-arch=gfx950 -> tarok_amd/libtarokenv.so (in-tree).
+
+    Safe when several ranks of one node start together: one process compiles (exclusive lock on a
+    side file), into a temporary name that is renamed over the library in one step; the others
+    wait, find the library current and return."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH, SRC]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():
+                tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+                cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
+                       "-I", os.path.join(ROOT, "include"), "-o", tmp, SRC]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.check_call(cmd)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
