@@ -216,35 +216,40 @@ class SelfPlay:
             env.step(buf["act"][t], auto_reset=True, obs_out=buf["words"][t + 1], reward_out=buf["reward"][t],
                      done_out=buf["done"][t])
 
+    def _collect_body(self, T):
+        """Everything one rollout does on the device, in launch order (captured as ONE graph: the
+        weight conversion and the buffer housekeeping are ~20 small launches that would otherwise
+        cost more host time than the 48 lock-steps take on the GPU)."""
+        buf = self._buf
+        self._refresh_rollout_weights()
+        buf["reward"].zero_()
+        buf["words"][0].copy_(self.obs_words)
+        self._rollout_body(T)
+        self.obs_words.copy_(buf["words"][T])
+
     @torch.no_grad()
     def collect(self, T):
         """T lock-steps of self-play into the static rollout buffers."""
         if self._buf is None or self._T != T:
             self._alloc(T)
-        self._refresh_rollout_weights()
         buf = self._buf
-        buf["reward"].zero_()
-        buf["words"][0].copy_(self.obs_words)
         if not self.use_graph:
-            self._rollout_body(T)
-        else:
-            if self._graph is None:
-                # warm up outside capture (lazy library / GEMM-workspace initialisation), then restore the env
-                s = torch.cuda.Stream(self.device)
-                s.wait_stream(torch.cuda.current_stream(self.device))
-                with torch.cuda.stream(s):
-                    self._rollout_body(2)             # an even number of env launches (refill-list parity)
-                torch.cuda.current_stream(self.device).wait_stream(s)
-                torch.cuda.synchronize(self.device)
-                buf["reward"].zero_()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._rollout_body(T)
-                self._graph = g
-                # the capture did not execute anything; continue from the warmed-up env state
-                buf["words"][0].copy_(buf["words"][2])
-            self._graph.replay()
-        self.obs_words = buf["words"][T].clone()
+            self._collect_body(T)
+            return buf
+        if self._graph is None:
+            # warm up outside capture (lazy library / GEMM-workspace initialisation, rollout copies of
+            # the weights allocated), then continue from the warmed-up env state
+            s = torch.cuda.Stream(self.device)
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                self._collect_body(2)                 # an even number of env launches (refill-list parity)
+            torch.cuda.current_stream(self.device).wait_stream(s)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._collect_body(T)
+            self._graph = g
+        self._graph.replay()
         return buf
 
     def update(self, buf, epochs=2, minibatches=8):
