@@ -11,7 +11,7 @@ One "step" = one lock-step of every game = one card played in each of the 65,536
 games of a rank (Tarok.py:48-56): legal mask of the seat to move, a uniform random
 legal card (the Bot policy, Igralec.py:158-159), the card applied, trick resolution
 and scoring, finished games replaced at once (auto-reset: every slot is live in
-every step), next observation written.  One kernel launch plays SIX TRICKS (24 such
+every step), next observation written.  One kernel launch plays TWELVE TRICKS (48 such
 steps; one trick = one pass of the reference's krog generator) with the state held in
 registers in between and every per-card output (action, observation word, done,
 scores) written to HBM; state is resident in HBM between launches.  One trick per
@@ -80,9 +80,9 @@ def main():
     ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--prefetch-every", type=int, default=0,
                     help="extra synchronous tarok_prefetch every k steps (0: none; the step launches refill the buffers themselves)")
-    ap.add_argument("--cards-per-launch", type=int, default=24,
+    ap.add_argument("--cards-per-launch", type=int, default=48,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
-                         "24 = six tricks; 1 = one card per launch)")
+                         "48 = twelve tricks; 1 = one card per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
     args = ap.parse_args()
@@ -169,7 +169,7 @@ def main():
                    "games_per_gpu": n,
                    "mode": "tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's "
                            "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps; "
-                           "finished games' successors (dealt four games ahead by the refill workgroups of the previous "
+                           "finished games' successors (dealt seven games ahead by the refill workgroups of the previous "
                            "launch) are swapped in inside the same launch" % (cards, chunk),
                    "cards_per_launch": cards,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},

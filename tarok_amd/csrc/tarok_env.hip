@@ -7,16 +7,16 @@
 // HBM bandwidth (no MFMA).
 //
 // Finished games are replaced at once (auto-reset) without a deal on the step's critical path:
-// every slot keeps its next FOUR games ready in the lines of its Aux record (episode e lives in
-// line e & 3).  A launch that consumes episode k pushes "deal k+4 into line k & 3" onto its
+// every slot keeps its next SEVEN games ready in the lines of its Aux record (episode e lives in
+// line e mod 7).  A launch that consumes episode k pushes "deal k+7 into line k mod 7" onto its
 // workgroup's refill list; the NEXT launch carries extra workgroups that work those lists off
-// (sorting-network deals on dense lanes) while its own play workgroups run — the ~4 us of deal
-// latency overlaps the next launch instead of following this one.  Four games ahead let a launch
-// play several tricks (the shortest game, a Berac lost on trick 1, is 4 cards) without ever
-// waiting for a deal.  Lists are double-buffered by launch parity; a line is valid iff its episode
-// tag matches and it is not being re-dealt right now (`cprev` in the slot's state), and a slot
-// that ever finds its line unusable just deals the game itself, wave-cooperatively
-// (ballot/readlane), same result.
+// (sorting-network deals on dense lanes) while its own play workgroups run — the ~5 us of deal
+// latency overlaps the next launch instead of following this one.  Seven games ahead let a launch
+// play up to twelve tricks (the shortest game, a Berac lost on trick 1, is 4 cards) practically
+// without ever waiting for a deal.  Lists are double-buffered by launch parity; a line is valid
+// iff its episode tag matches and it is not being re-dealt right now (`cprev` in the slot's
+// state), and a slot that ever runs out of usable lines just deals the game itself,
+// wave-cooperatively (ballot/readlane), same result.
 #include "tarok_device.h"
 
 #include <hip/hip_runtime.h>
@@ -28,13 +28,16 @@
 
 #define TK_BLOCK 256
 #define TK_PF_SLOTS 1024
-#define TK_REFILL_CAP 1024         // refill-list entries per play workgroup and launch (<= 4 per slot)
+#define TK_REFILL_CAP (256 * TK_AHEAD) // refill-list entries per play workgroup and launch (<= TK_AHEAD per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 // list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
 // different XCDs, whose L2s are not coherent: two of them must never write into one line
 #define TK_RC(group, par) ((((size_t)(group)) * 2 + (par)) * 32)
 
-#define TK_AHEAD 4                  // next-game lines per slot
+#ifndef TK_AHEAD
+#define TK_AHEAD 7                  // next-game lines per slot (<= 7: epar and cprev are 3 bits each)
+#endif
+#define TK_LINE(episode) ((u32)(episode) % (u32)TK_AHEAD)
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 
@@ -46,7 +49,8 @@ struct __attribute__((aligned(64))) AuxLine {
     u32 pad[5];
 };
 struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
-static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 256, "Aux must be four cache lines");
+static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 64 * TK_AHEAD, "one cache line per next-game line");
+static_assert(TK_AHEAD >= 2 && TK_AHEAD <= 7, "epar / cprev are 3-bit fields");
 // What a finishing game always touches: the slot's episode number and its summed scores.  Kept
 // apart from the next-game lines: those are written by refill workgroups, these by the slot's own
 // play workgroup, which runs on another XCD (another, non-coherent L2) — the two must not share
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     }
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 3; g.cprev = 0;
+    g.epar = TK_LINE(episode); g.cprev = 0;
     if (g.phase == TK_PHASE_EXCHANGE && !(flags & TAROK_DEFER_EXCHANGE)) {
         if (choice && discards) {
             const uint8_t *q = discards + i * 3;
@@ -174,11 +178,11 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
     sample_setup(key, mix, c, d, k);
     Game g;
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
-    g.epar = episode & 3; g.cprev = 0;
+    g.epar = TK_LINE(episode); g.cprev = 0;
     if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
     ulonglong2 a, b;
     pack(g, a.x, a.y, b.x, b.y);
-    AuxLine *ln = &aux[j].line[episode & 3];
+    AuxLine *ln = &aux[j].line[TK_LINE(episode)];
     ln->n01 = a; ln->n23 = b; ln->nkey = key; ln->nep = episode;
 }
 
@@ -196,11 +200,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
     __syncthreads();
     u32 f = reinterpret_cast<const u32 *>(nstale + base)[threadIdx.x];   // 4 slots; array is padded
     if (f) {
-        u32 c = __popc(f & 0x0F0F0F0Fu);
+        u32 c = __popc(f & (0x01010101u * ((1u << TK_AHEAD) - 1)));
         u32 pos = atomicAdd(&count, c);
 #pragma unroll
         for (u32 k = 0; k < 4; k++) {
-            u32 fk = (f >> (8 * k)) & 15;
+            u32 fk = (f >> (8 * k)) & ((1u << TK_AHEAD) - 1);
 #pragma unroll
             for (u32 b = 0; b < TK_AHEAD; b++)
                 if (fk & (1u << b)) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * TK_AHEAD + b);
@@ -346,11 +350,11 @@ __device__ __forceinline__ void play_role(
         acc = cnt[i].score_sum;
         cur_ep = cnt[i].episode;
         if (autoreset && allowed > 0) {
-            const AuxLine *ln = &aux[i].line[(g.epar + 1) & 3];
+            const AuxLine *ln = &aux[i].line[TK_LINE(g.epar + 1)];
             na = ln->n01; nb = ln->n23; nkey = ln->nkey;
             u32 nep = ln->nep, nep2 = 0xFFFFFFFFu;
             if (allowed > 1 && cards > 4) {          // a Berac can be over after 4 cards
-                const AuxLine *l2 = &aux[i].line[(g.epar + 2) & 3];
+                const AuxLine *l2 = &aux[i].line[TK_LINE(g.epar + 2)];
                 na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey; nep2 = l2->nep;
             }
             ok1 = nep == cur_ep + 1;
@@ -360,7 +364,8 @@ __device__ __forceinline__ void play_role(
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
-    bool resync = false;                    // a game was dealt in place: the lines are out of step
+    bool resync = false;                    // a line that should have been usable was not: refill them all
+    bool blocked = false;                   // a game was dealt in place: no more swap-ins in this launch
     bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
@@ -390,14 +395,14 @@ __device__ __forceinline__ void play_role(
         if (autoreset) {
             bool renew = valid && g.phase == TK_PHASE_DONE;
             if (__ballot(renew)) {
-                if (renew && !resync && !ok1 && consumed >= 1 && consumed < allowed) {
+                if (renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed) {
                     // third game of a launch (or second, when one line was loaded): fetch it now
-                    const AuxLine *ln = &aux[i].line[(cur_ep + 1) & 3];
+                    const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
                     na = ln->n01; nb = ln->n23; nkey = ln->nkey;
                     ok1 = ln->nep == cur_ep + 1;
                     TK_WAIT_LOADS();
                 }
-                bool swap = renew && !resync && ok1;
+                bool swap = renew && !blocked && ok1;
                 if (swap) {
                     unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game, cprev = 0
                     key = nkey;
@@ -406,6 +411,10 @@ __device__ __forceinline__ void play_role(
                     ok2 = false;
                 }
                 bool deal_here = renew && !swap;             // line missing, stale or being re-dealt
+                // ran out of usable lines (the next ones are being re-dealt right now: the usual
+                // bookkeeping stays valid) vs a line that should have been there and is not
+                if (deal_here && consumed < allowed) resync = true;
+                if (deal_here) blocked = true;
                 u64 pend = __ballot(deal_here);
                 if (pend) {
                     u64 dkey = 0;
@@ -425,10 +434,9 @@ __device__ __forceinline__ void play_role(
                         u32 cc, d, k;
                         sample_setup(dkey, mix, cc, d, k);
                         setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
-                        g.epar = (cur_ep + 1) & 3; g.cprev = 0;
+                        g.epar = TK_LINE(cur_ep + 1); g.cprev = 0;
                         if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
                         key = dkey;
-                        resync = true;                       // refill all the lines after this launch
                     }
                 }
                 if (renew) { cur_ep++; consumed++; seats_dirty = true; }
@@ -1124,8 +1132,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.team = (u32)(m >> 42) & 15;
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
-    g.epar = cnt[i].episode & 3;
-    g.cprev = (u32)(s23[i].y >> 60) & 7;            // lines on a refill list stay off limits for the next launch
+    g.epar = TK_LINE(cnt[i].episode);
+    g.cprev = (u32)(s23[i].y >> 61) & 7;            // lines on a refill list stay off limits for the next launch
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
     u64 seatc[4];

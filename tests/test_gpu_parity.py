@@ -266,7 +266,7 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
     for cards, chunk, pf in [(0, 48, 4), (1, 0, 0), (1, 64, 16), (0, 0, 2),
                              (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0), (8, 64, 0), (12, 48, 0),
-                             (24, 192, 0), (24, 96, 0), (32, 192, 0)]:       # 24 / 192 / 0 is the bench's headline mode
+                             (24, 192, 0), (24, 96, 0), (32, 192, 0), (48, 192, 0), (48, 96, 0)]:   # 48 / 192 / 0 is the bench's headline mode
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
@@ -286,13 +286,13 @@ def test_krog_kernel_writes_what_four_single_steps_write(T, S):
     # (the last case: more workgroups than fit on the chip at once and an N that puts workgroup
     #  boundaries inside cache lines of the byte-sized output rows)
     for auto, cards, lead_in, n in [(True, 4, 0, 16384), (True, 4, 2, 16384), (False, 4, 0, 16384), (True, 8, 1, 16384),
-                                    (True, 5, 0, 16384), (True, 24, 0, 16384), (True, 24, 3, 16384), (True, 24, 0, 300007)]:
+                                    (True, 5, 0, 16384), (True, 24, 0, 16384), (True, 24, 3, 16384), (True, 48, 0, 16384), (True, 48, 1, 300007)]:
         a = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         b = T.TarokVecEnv(n, seed=19, mix=S.MIX_ALL)
         a.reset(); b.reset()
         for t in range(lead_in):
             a.step_random(auto_reset=auto); b.step_random(auto_reset=auto)
-        for rounds in range(14 if cards < 24 else 6):
+        for rounds in range(14 if cards < 24 else (6 if cards < 48 else 3)):
             kb = a.krog_random(cards, auto_reset=auto)
             for c in range(cards):
                 ob, rw, dn = b.step_random(auto_reset=auto, tricks=True)
@@ -697,14 +697,14 @@ def test_four_million_games_rollout_bit_exact(T, O, S):
 
 
 def test_million_games_headline_mode_vs_oracle(T, O, S):
-    """The bench's mode (24 cards per launch, graph-replayed, auto-reset) on 2^20 games of a shard
+    """The bench's mode (48 cards per launch, graph-replayed, auto-reset) on 2^20 games of a shard
     that does not start at game 0: episode numbers, score sums, canonical state and observation
-    words after 96 lock-steps vs the oracle."""
-    n, seed, steps, off = 1 << 20, 5, 96, 987654321
+    words after 192 lock-steps vs the oracle."""
+    n, seed, steps, off = 1 << 20, 5, 192, 987654321
     ref = O.run_autoreset(seed, off, n, S.MIX_ALL, steps)
     env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, game_offset=off)
     env.reset()
-    env.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+    env.run_random(steps, cards_per_launch=48, graph_chunk=96, auto_reset=True)
     ep, ss = env.counters()
     assert (ep == ref["episode"]).all()
     assert (ss == ref["score_sum"]).all()
@@ -714,7 +714,7 @@ def test_million_games_headline_mode_vs_oracle(T, O, S):
 
 
 def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S):
-    """2^22 games, 24 cards per launch, 96 lock-steps: two runs give identical counters and state
+    """2^22 games, 48 cards per launch, 96 lock-steps: two runs give identical counters and state
     (no launch-order or cache-placement dependence), and the third quarter of the batch equals a
     2^20-game env created on that shard alone."""
     n, steps = 1 << 22, 96
@@ -722,7 +722,7 @@ def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S
     for rep in range(2):
         env = T.TarokVecEnv(n, seed=9, mix=S.MIX_ALL)
         env.reset()
-        env.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+        env.run_random(steps, cards_per_launch=48, graph_chunk=96, auto_reset=True)
         ep, ss = env.counters()
         res.append((ep.copy(), ss.copy(), env.state().copy()))
         env.close()
@@ -730,7 +730,7 @@ def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S
     q = n // 4
     part = T.TarokVecEnv(q, seed=9, mix=S.MIX_ALL, game_offset=2 * q)
     part.reset()
-    part.run_random(steps, cards_per_launch=24, graph_chunk=48, auto_reset=True)
+    part.run_random(steps, cards_per_launch=48, graph_chunk=96, auto_reset=True)
     ep, ss = part.counters()
     assert (ep == res[0][0][2 * q:3 * q]).all() and (ss == res[0][1][2 * q:3 * q]).all()
     assert (part.state() == res[0][2][:, 2 * q:3 * q]).all()

@@ -25,7 +25,8 @@ else:
              (1 << 20, 0, 4, 96, 48, None), (1 << 20, 0, 24, 96, 0, None), (1 << 20, 0, 24, 48, 0, None),
              # one card per launch, the two-kernel external-policy path, ragged N
              (1 << 20, 0, 1, 96, 48, None), (1 << 20, 0, 0, 96, 48, None), (1 << 20, 5, 0, 64, 0, None),
-             (1000003, 77, 24, 96, 48, None), (1000003, 77, 1, 64, 0, None), (1 << 22, 0, 24, 48, 48, None)]
+             (1000003, 77, 24, 96, 48, None), (1000003, 77, 1, 64, 0, None), (1 << 22, 0, 24, 48, 48, None),
+             (1 << 20, 11, 48, 192, 96, None), (1000003, 77, 48, 96, 96, None), (1 << 22, 0, 48, 96, 96, None), (1 << 20, 0, 48, 96, 0, "1")]
     for n, off, cards, steps, chunk, fan in cases:
         env = dict(os.environ)
         if fan: env["TAROK_REFILL_FAN"] = fan

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench.err || exit 1
 echo "bench done"; cat $OUT/bench_line.json | cut -c1-400
-# headline mode only: every k_play<true> dispatch in this trace is a 24-card launch of the timed mode
+# headline mode only: every k_play<true> dispatch in this trace is a 48-card launch of the timed mode
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --no-cpu-baseline --no-extras > $OUT/stats_bench.json 2> $OUT/stats.err || exit 1
 # all modes (one trick / one card / two-kernel / rollout / self-play side measurements)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_all -- python3 bench.py --no-cpu-baseline > $OUT/stats_all_bench.json 2> $OUT/stats_all.err || exit 1
@@ -16,14 +16,14 @@ echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 960 --warmup 192 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 960 --warmup 192 --no-cpu-baseline --no-extras > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
 echo "pmc done"
-python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 24 65536 $OUT/pmc_fetch_write_65536.json
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 48 65536 $OUT/pmc_fetch_write_65536.json
 for N in 65536 1048576 4194304 16777216; do
   python3 bench.py --games $N --steps 384 --warmup 192 --no-cpu-baseline --no-extras > $OUT/bench_N$N.json 2>> $OUT/nsweep.err || exit 1
   cut -c1-200 $OUT/bench_N$N.json
 done
 bash tools/sq_counters.sh 4194304 $TAG/sq4m > /dev/null 2>&1 && cp gpurun_out/$TAG/sq4m/sq_counters.json $OUT/sq_counters_4194304.json
 python3 tools/mlp_time.py 65536 > $OUT/policy_mlp_times.txt 2>&1
-python3 tools/krog_stamps.py 65536 24 > $OUT/wave_stamps_65536.txt 2>&1
+python3 tools/krog_stamps.py 65536 48 > $OUT/wave_stamps_65536.txt 2>&1
 python3 tools/pf_sweep.py 65536 > $OUT/cards_per_launch_sweep.json 2>&1
 # keep only the summaries of the rocprof directories (the raw traces are large)
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;

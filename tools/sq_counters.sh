@@ -16,7 +16,7 @@ for p in ("p1", "p2"):
         for k, v in acc.items():
             v = v[len(v) // 2:]          # steady state: second half of the launches
             res[k] = {"launches": len(v), "mean": sum(v) / len(v)}
-res["games"] = $N; res["cards_per_launch"] = 24
+res["games"] = $N; res["cards_per_launch"] = 48
 json.dump(res, open("$OUT/sq_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
