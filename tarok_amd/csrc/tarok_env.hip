@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/tarok_env.h"
 
@@ -370,9 +371,12 @@ __device__ __forceinline__ void play_role(
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
-    int64_t row = i;
-    for (int c = 0; c < cards; c++, row += stride) {
-        bool play = valid && g.phase == TK_PHASE_PLAY;
+    auto play_card = [&](auto all_tag, int64_t row) __attribute__((always_inline)) {
+        // ALL: every lane of the wave is a valid slot with a game in play (wave uniform, see below):
+        // no per-lane predicates around the rules and the output stores
+        constexpr bool ALL = decltype(all_tag)::value;
+        const bool v = ALL ? true : valid;
+        const bool play = ALL ? true : (valid && g.phase == TK_PHASE_PLAY);
         u32 a = a_in;
         if (RANDOM) a = play ? policy_action(key, g.trick_no * 4 + g.nt, legal) : 255u;
         u64 scores = 0;
@@ -382,7 +386,7 @@ __device__ __forceinline__ void play_role(
         bool fin = res == 1;
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
-        if (valid) {
+        if (v) {
             if (RANDOM && action_out) action_out[row] = (uint8_t)a;
             if (trick) trick[row] = (uint16_t)trick_info;
         }
@@ -393,7 +397,7 @@ __device__ __forceinline__ void play_role(
             acc_dirty = true;
         }
         if (autoreset) {
-            bool renew = valid && g.phase == TK_PHASE_DONE;
+            bool renew = v && g.phase == TK_PHASE_DONE;
             if (__ballot(renew)) {
                 if (renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed) {
                     // third game of a launch (or second, when one line was loaded): fetch it now
@@ -442,11 +446,20 @@ __device__ __forceinline__ void play_role(
                 if (renew) { cur_ep++; consumed++; seats_dirty = true; }
             }
         }
-        if (RANDOM) legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
-        if (valid) {
+        if (RANDOM) legal = (v && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+        if (v) {
             obs[row] = RANDOM ? obs_word_with(g, fin, legal) : obs_word(g, fin);
             if (done) done[row] = fin ? 1 : 0;
         }
+    };
+    // With auto-reset a lane that is in play stays in play (a finished game is replaced within the
+    // same card), so "every lane of the wave valid and in play" decided HERE holds for the whole
+    // launch: one of two separate loops (a choice per card made the loop body slower than either).
+    int64_t row = i;
+    if (autoreset && __ballot(valid && g.phase == TK_PHASE_PLAY) == ~0ULL) {
+        for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, row);
+    } else {
+        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, row);
     }
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+4.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
