@@ -365,6 +365,9 @@ __device__ __forceinline__ void play_role(
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
+#ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
+    u32 ev_deal = 0, ev_lazy = 0, ev_renew = 0;
+#endif
     bool resync = false;                    // a line that should have been usable was not: refill them all
     bool blocked = false;                   // a game was dealt in place: no more swap-ins in this launch
     bool acc_dirty = false, seats_dirty = false, touched = false;
@@ -399,6 +402,10 @@ __device__ __forceinline__ void play_role(
         if (autoreset) {
             bool renew = v && g.phase == TK_PHASE_DONE;
             if (__ballot(renew)) {
+#ifdef TK_EVENT_STAMPS
+                ev_renew++;
+                if (__ballot(renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed)) ev_lazy++;
+#endif
                 if (renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed) {
                     // third game of a launch (or second, when one line was loaded): fetch it now
                     const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
@@ -421,6 +428,9 @@ __device__ __forceinline__ void play_role(
                 if (deal_here) blocked = true;
                 u64 pend = __ballot(deal_here);
                 if (pend) {
+#ifdef TK_EVENT_STAMPS
+                    ev_deal += (u32)__popcll(pend);
+#endif
                     u64 dkey = 0;
                     if (deal_here) dkey = game_key(seed, offset + (u64)i, cur_ep + 1);
                     u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
@@ -487,6 +497,9 @@ __device__ __forceinline__ void play_role(
         stamps[3 * w + 0] = t_real0;
         stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
+#ifdef TK_EVENT_STAMPS                      // (replaces the entry time stamp)
+        stamps[3 * w + 0] = ((u64)ev_deal << 48) | ((u64)ev_lazy << 32) | ((u64)ev_renew << 16) | (u64)__popcll(__ballot(consumed > 0));
+#endif
     }
 }
 

@@ -1,8 +1,19 @@
-import sys, os, ctypes as C
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): what makes a play wave slow?  Builds the library with -DTK_EVENT_STAMPS (per-wave
+counts of in-place deals, late line fetches and finishing events next to the cycle stamps), plays 48-card
+launches at 65,536 games and correlates the counts with the waves' cycle counts."""
+import sys, os, subprocess, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if not os.environ.get("TAROK_LIB"):
+    lib = os.path.join(ROOT, "gpurun_out", "libtarokenv_events.so")
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DTK_EVENT_STAMPS",
+                           "-I", os.path.join(ROOT, "include"), "-o", lib, os.path.join(ROOT, "tarok_amd", "csrc", "tarok_env.hip")])
+    os.environ["TAROK_LIB"] = lib
 import numpy as np, torch
 from tarok_amd import TarokVecEnv, karte as K, _native
-n, cards = 65536, 24
+n, cards = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 48
 env = TarokVecEnv(n, seed=0, mix=K.MIX_ALL)
 env.reset()
 env.run_random(960, cards_per_launch=cards, graph_chunk=192, auto_reset=True)
