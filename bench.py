@@ -205,6 +205,28 @@ def main():
                                    "the N-sweep and the VALU-issue ceiling"
                                    % (n, cards)}
 
+    if rank == 0:
+        # ---- what actually bounds the kernel: the VALU instruction count per step,
+        # from the committed SQ counter passes of this kernel (tools/sq_counters.sh: 4 M games, where
+        # the vector ALUs are busy ~96 % of the launch).  Ceiling = SIMDs x clock / 4 cycles per
+        # wave64 instruction x 64 lanes / instructions per step; reported beside the HBM roofline.
+        sq = os.path.join(ROOT, "profiles", "r01_sq_counters_4194304.json")
+        if os.path.exists(sq):
+            with open(sq) as f:
+                c = json.load(f)
+            if c.get("cards_per_launch") == cards and "SQ_INSTS_VALU" in c:
+                waves = c["games"] / 64.0 * c["cards_per_launch"]
+                per_step = c["SQ_INSTS_VALU"]["mean"] / waves
+                ceiling = 1024 * 2.3e9 / 4.0 * 64.0 / per_step
+                out["issue_roofline"] = {"bound": "valu", "valu_instructions_per_step": per_step,
+                                         "all_instructions_per_step": (c["SQ_INSTS_VALU"]["mean"] + c["SQ_INSTS_SALU"]["mean"] +
+                                                                       c["SQ_INSTS_BRANCH"]["mean"] + c["SQ_INSTS_VMEM_WR"]["mean"] +
+                                                                       c["SQ_INSTS_VMEM_RD"]["mean"]) / waves,
+                                         "valu_busy_at_4M_games": c["SQ_ACTIVE_INST_VALU"]["mean"] * 4.0 / (1024 * c["GRBM_GUI_ACTIVE"]["mean"] / 8.0),
+                                         "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
+                                         "source": "profiles/r01_sq_counters_4194304.json",
+                                         "note": "1024 SIMDs x 2.3 GHz / 4 cycles x 64 lanes / VALU instructions per step"}
+
     if not args.no_extras:
         # ---- side measurements (not `value`)
         # (a) the two-kernel C-ABI path: tarok_policy_random writes the action array, tarok_step consumes it
