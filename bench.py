@@ -64,7 +64,13 @@ def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
     t1 = time.perf_counter()
     r1 = O.rollout(0, 0, n_games_chunk // 8, 0, mix, threads=1, trace=False)
     dt1 = time.perf_counter() - t1
-    return {"value": steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": steps / dt, "unit": "env steps/s", "cores": cores, "cpu_model": model, "kind": "port",
             "sample": "%d random-policy games (%d steps) of the mixed-contract workload, C oracle, %d threads, %.1f s"
                       % (games, steps, cores, dt),
             "single_core_value": r1["total_steps"] / dt1}
