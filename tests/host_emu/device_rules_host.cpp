@@ -7,7 +7,46 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// Replay mode: recorded games of the reference engine (tests/golden/traces_v1.npz, flattened by the
+// test into records {deal[54], contract, declarer, king, choice, discards[3], nsteps, actions[48]}):
+// explicit deal -> setup_game -> apply_exchange -> apply_step<false> card by card; writes seats,
+// legal masks, per-trick info, return codes and final scores for comparison with the fixture.
+static int replay(const char *in, const char *out) {
+    FILE *fi = fopen(in, "rb"), *fo = fopen(out, "wb");
+    if (!fi || !fo) return 3;
+    struct Rec { uint8_t deal[54]; int8_t contract, declarer, king, choice; uint8_t discards[3]; uint8_t nsteps; uint8_t actions[48]; } rec;
+    static_assert(sizeof(Rec) == 110, "packed record");
+    while (fread(&rec, sizeof rec, 1, fi) == 1) {
+        u64 h[4] = {0, 0, 0, 0}, tal = 0;
+        for (int k = 0; k < 48; k++) h[k / 12] |= 1ULL << rec.deal[k];
+        for (int k = 0; k < 6; k++) tal |= (u64)rec.deal[48 + k] << (6 * k);
+        Game g;
+        setup_game(g, h[0], h[1], h[2], h[3], tal, (u32)rec.contract, (u32)rec.declarer, rec.king < 0 ? 0u : (u32)rec.king);
+        g.epar = 0; g.cprev = 0;
+        int8_t ok = 1;
+        if (g.phase == TK_PHASE_EXCHANGE) ok = apply_exchange(g, (u32)rec.choice, rec.discards[0], rec.discards[1], rec.discards[2]) ? 1 : 0;
+        int8_t seats[48]; u64 masks[48]; uint16_t tinfo[48]; int8_t rc[48];
+        u64 scores = 0;
+        for (int t = 0; t < 48; t++) {
+            seats[t] = -1; masks[t] = 0; tinfo[t] = 0; rc[t] = -2;
+            if (t < rec.nsteps && g.phase == TK_PHASE_PLAY) {
+                seats[t] = (int8_t)((g.leader + g.nt) & 3);
+                masks[t] = legal_now(g);
+                u32 ti = 0;
+                rc[t] = (int8_t)apply_step<false>(g, rec.actions[t], scores, ti);
+                tinfo[t] = (uint16_t)ti;
+            }
+        }
+        int8_t done = g.phase == TK_PHASE_DONE;
+        fwrite(&ok, 1, 1, fo); fwrite(&done, 1, 1, fo); fwrite(seats, 1, 48, fo); fwrite(masks, 8, 48, fo);
+        fwrite(tinfo, 2, 48, fo); fwrite(rc, 1, 48, fo); fwrite(&scores, 8, 1, fo);
+    }
+    fclose(fi); fclose(fo);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 4 && argv[1][0] == 'r') return replay(argv[2], argv[3]);
     if (argc < 7) { fprintf(stderr, "usage: %s seed offset n episode mix out.bin\n", argv[0]); return 2; }
     u64 seed = strtoull(argv[1], 0, 10), offset = strtoull(argv[2], 0, 10);
     long n = atol(argv[3]);

@@ -40,3 +40,47 @@ def test_device_rules_on_the_host_equal_the_oracle(host_binary, tmp_path, mix, s
     assert (got["seats"][live] == ref["seats"][live]).all()
     assert (got["actions"][live] == ref["actions"][live]).all()
     assert (got["masks"][~live] == 0).all()
+
+
+def test_device_rules_on_the_host_replay_the_reference_traces(host_binary, tmp_path):
+    """The 2,880 games recorded from the reference engine (tests/golden/traces_v1.npz: all ten
+    contracts, recorded exchanges and cards) replayed card by card through the device rule code on
+    the CPU: every seat, legal mask (`mozne`), per-trick winner and value, the game length and the
+    final scores equal what the reference produced."""
+    from oracle import tarok_spec as S
+    tr = np.load(os.path.join(ROOT, "tests", "golden", "traces_v1.npz"))
+    n = len(tr["contract"])
+    rec = np.dtype([("deal", np.uint8, 54), ("contract", np.int8), ("declarer", np.int8), ("king", np.int8), ("choice", np.int8),
+                    ("discards", np.uint8, 3), ("nsteps", np.uint8), ("actions", np.uint8, 48)])
+    assert rec.itemsize == 110
+    a = np.zeros(n, rec)
+    a["deal"] = tr["deals"]; a["contract"] = tr["contract"]; a["declarer"] = tr["declarer"]; a["king"] = tr["king"]
+    a["choice"] = np.where(tr["choice"] < 0, 0, tr["choice"])
+    disc = np.array(tr["discards"]).astype(np.int64)
+    ndisc = np.array([S.N_DISCARD[int(c)] for c in tr["contract"]])
+    disc = np.where(np.arange(3)[None, :] < ndisc[:, None], disc, 255)          # unused slots: no card
+    a["discards"] = disc.astype(np.uint8)
+    a["nsteps"] = tr["nsteps"]
+    acts = np.array(tr["actions"]).astype(np.int64)
+    a["actions"] = np.where(acts < 0, 255, acts).astype(np.uint8)
+    pin, pout = str(tmp_path / "traces.bin"), str(tmp_path / "replayed.bin")
+    a.tofile(pin)
+    subprocess.check_call([host_binary, "replay", pin, pout])
+    out = np.dtype([("ok", np.int8), ("done", np.int8), ("seats", np.int8, 48), ("masks", np.uint64, 48), ("tinfo", np.uint16, 48),
+                    ("rc", np.int8, 48), ("scores", np.int16, 4)])
+    got = np.fromfile(pout, dtype=out)
+    assert got.shape == (n,)
+    assert (got["ok"] == 1).all() and (got["done"] == 1).all()
+    nst = tr["nsteps"].astype(np.int64)
+    live = np.arange(48)[None, :] < nst[:, None]
+    assert (got["seats"][live] == tr["seats"][live]).all()
+    assert (got["masks"][live] == tr["masks"][live].astype(np.uint64)).all()
+    last = np.arange(48)[None, :] == (nst[:, None] - 1)
+    assert (got["rc"][live & ~last] == 0).all() and (got["rc"][last] == 1).all()
+    assert (got["scores"] == tr["scores"]).all()
+    # what rezultat_stiha was told after every 4th card: 0x8000 | vrednost_stiha << 4 | winner seat
+    for k in range(12):
+        t = 4 * k + 3
+        sel = nst > t
+        exp = 0x8000 | (tr["trick_value"][sel, k].astype(np.int64) << 4) | tr["trick_winner"][sel, k].astype(np.int64)
+        assert (got["tinfo"][sel, t].astype(np.int64) == exp).all(), k
