@@ -84,3 +84,13 @@ def test_device_rules_on_the_host_replay_the_reference_traces(host_binary, tmp_p
         sel = nst > t
         exp = 0x8000 | (tr["trick_value"][sel, k].astype(np.int64) << 4) | tr["trick_winner"][sel, k].astype(np.int64)
         assert (got["tinfo"][sel, t].astype(np.int64) == exp).all(), k
+
+
+def test_device_rules_under_address_and_ub_sanitizers(tmp_path):
+    """The same host build with -fsanitize=address,undefined (GPU sanitizers are not available on the
+    pool: the CPU build is where the rule code's shifts, indexing and integer arithmetic are checked)."""
+    exe = str(tmp_path / "device_rules_host_san")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", EMU, "-o", exe, os.path.join(EMU, "device_rules_host.cpp")])
+    for mix, seed in ((0, 5), (2, 9), (25, 1)):
+        subprocess.check_call([exe, str(seed), "0", "1500", "0", str(mix), str(tmp_path / "o.bin")])
