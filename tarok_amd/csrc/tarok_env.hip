@@ -374,10 +374,14 @@ __device__ __forceinline__ void play_role(
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
-    auto play_card = [&](auto all_tag, int64_t row) __attribute__((always_inline)) {
+    auto play_card = [&](auto all_tag, auto nt_tag, int64_t row) __attribute__((always_inline)) {
         // ALL: every lane of the wave is a valid slot with a game in play (wave uniform, see below):
-        // no per-lane predicates around the rules and the output stores
+        // no per-lane predicates around the rules and the output stores.
+        // NT >= 0: moreover every lane is at card NT of its trick: the constant propagates through
+        // the rules (no trick-end test on cards 0..2, constant shifts, "somebody led" known)
         constexpr bool ALL = decltype(all_tag)::value;
+        constexpr int NT = decltype(nt_tag)::value;
+        if constexpr (NT >= 0) g.nt = (u32)NT;
         const bool v = ALL ? true : valid;
         const bool play = ALL ? true : (valid && g.phase == TK_PHASE_PLAY);
         u32 a = a_in;
@@ -393,13 +397,15 @@ __device__ __forceinline__ void play_role(
             if (RANDOM && action_out) action_out[row] = (uint8_t)a;
             if (trick) trick[row] = (uint16_t)trick_info;
         }
-        if (fin) {
+        // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
+        constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
+        if (CAN_END && fin) {
             if (reward) reinterpret_cast<u64 *>(reward)[row] = scores;
             acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
             acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
             acc_dirty = true;
         }
-        if (autoreset) {
+        if (CAN_END && autoreset) {
             bool renew = v && g.phase == TK_PHASE_DONE;
             if (__ballot(renew)) {
 #ifdef TK_EVENT_STAMPS
@@ -465,11 +471,23 @@ __device__ __forceinline__ void play_role(
     // With auto-reset a lane that is in play stays in play (a finished game is replaced within the
     // same card), so "every lane of the wave valid and in play" decided HERE holds for the whole
     // launch: one of two separate loops (a choice per card made the loop body slower than either).
+    // Games are whole tricks long, so lanes that start a launch of whole tricks at a trick boundary
+    // stay trick-aligned too: third loop, four specialised cards per trick.
     int64_t row = i;
+    typedef std::integral_constant<int, -1> nt_any;
     if (autoreset && __ballot(valid && g.phase == TK_PHASE_PLAY) == ~0ULL) {
-        for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, row);
+        if ((cards & 3) == 0 && __ballot(g.nt != 0) == 0) {
+            for (int c = 0; c < cards; c += 4) {
+                play_card(std::true_type{}, std::integral_constant<int, 0>{}, row); row += stride;
+                play_card(std::true_type{}, std::integral_constant<int, 1>{}, row); row += stride;
+                play_card(std::true_type{}, std::integral_constant<int, 2>{}, row); row += stride;
+                play_card(std::true_type{}, std::integral_constant<int, 3>{}, row); row += stride;
+            }
+        } else {
+            for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, row);
+        }
     } else {
-        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, row);
+        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, row);
     }
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+4.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
@@ -503,8 +521,10 @@ __device__ __forceinline__ void play_role(
     }
 }
 
+// (at most 128 VGPRs: four waves per SIMD for the throughput-bound batch sizes; the specialised
+// card loops would otherwise take 131)
 template <bool RANDOM>
-__global__ __launch_bounds__(TK_BLOCK) void k_play(
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
