@@ -554,13 +554,17 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
     setup_game(g, h0, h1, h2, h3, tal, c, d, k);
     if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
     u64 scores = 0;
-    int t = 0, played = 0;
-    for (; t < 48; t++) {
+    int played = 0;
+    // one card; NT = its position in the trick, a compile-time constant (every lane starts its game
+    // at a trick boundary and plays one card per step): see play_role's trick-aligned loop
+    auto card = [&](auto nt_tag, int t) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_tag)::value;
         bool live = g.phase == TK_PHASE_PLAY;
         u64 m = 0;
         u32 a = 255;
         int seat = -1;
         if (live) {
+            g.nt = (u32)NT;
             m = legal_now(g);
             seat = (int)((g.leader + g.nt) & 3);
             a = policy_action(key, (u32)t, m);
@@ -571,6 +575,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
         if (seats) seats[(int64_t)t * n + i] = (int8_t)seat;
         if (masks) masks[(int64_t)t * n + i] = m;
         if (actions) actions[(int64_t)t * n + i] = (uint8_t)a;
+    };
+    for (int t = 0; t < 48; t += 4) {
+        card(std::integral_constant<int, 0>{}, t);
+        card(std::integral_constant<int, 1>{}, t + 1);
+        card(std::integral_constant<int, 2>{}, t + 2);
+        card(std::integral_constant<int, 3>{}, t + 3);
     }
     if (scores_out) reinterpret_cast<u64 *>(scores_out)[i] = scores;
     if (nsteps_out) nsteps_out[i] = (int16_t)played;
