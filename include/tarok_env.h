@@ -232,6 +232,13 @@ int tarok_policy_step(tarok_env *env, const void *w1, const float *b1, const voi
                       float *logp_out, float *value_out, uint64_t *feature_words_out, int16_t *reward_out,
                       uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
+/* The learner's network input for a minibatch: features_out[j] [256] bf16 (0.0 / 1.0) = the bits
+ * of feature_words[index[j]] (feature_words [M,4] u64 as written by feature_words_out; index
+ * [n_samples] i64 sample numbers, or NULL for samples 0..n_samples-1).  Gather + expansion in one
+ * pass. */
+int tarok_expand_features(tarok_env *env, int64_t n_samples, const uint64_t *feature_words,
+                          const int64_t *index, void *features_out, void *stream);
+
 /* The learner's loss for the policy above, forward and gradient in one pass: clipped-surrogate
  * policy loss + value loss - entropy bonus over the LEGAL cards of every sample (build-owned:
  * the reference has no policy-gradient learner).

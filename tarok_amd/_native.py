@@ -18,7 +18,7 @@ SYMBOLS = [
     "tarok_strerror", "tarok_abi_version", "tarok_device_count", "tarok_last_hip_error",
     "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_reset", "tarok_exchange",
     "tarok_legal_actions", "tarok_step", "tarok_prefetch", "tarok_policy_random", "tarok_step_random",
-    "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy", "tarok_policy_mlp", "tarok_policy_step", "tarok_ppo_loss",
+    "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy", "tarok_policy_mlp", "tarok_policy_step", "tarok_expand_features", "tarok_ppo_loss",
 ]
 
 
@@ -123,6 +123,7 @@ def lib():
     L.tarok_sample_policy.restype = i32; L.tarok_sample_policy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tarok_policy_mlp.restype = i32; L.tarok_policy_mlp.argtypes = [vp] * 14
     L.tarok_policy_step.restype = i32; L.tarok_policy_step.argtypes = [vp] * 16 + [i32, vp]
+    L.tarok_expand_features.restype = i32; L.tarok_expand_features.argtypes = [vp, i64, vp, vp, vp, vp]
     f32 = C.c_float
     L.tarok_ppo_loss.restype = i32; L.tarok_ppo_loss.argtypes = [vp, i64] + [vp] * 7 + [f32] * 3 + [vp] * 4
     L.tarok_debug_stamps.restype = i32; L.tarok_debug_stamps.argtypes = [vp, vp]

@@ -693,6 +693,28 @@ __global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__r
 
 
 // ---------------------------------------------------------------------------
+// Learner side: a minibatch of network inputs from the rollout's 32-byte feature words
+// (tarok_policy_mlp / tarok_policy_step feature_words_out): out[j] = the 256 bf16 0/1 features
+// of sample index[j] (or of sample j when index is NULL).  One 16-byte chunk (one byte of a
+// feature word -> 8 bf16) per thread, 32 threads per sample: the gather and the expansion in one
+// pass, full 512-byte rows written per 32 lanes.
+__global__ __launch_bounds__(TK_BLOCK) void k_expand_features(int64_t n, const u64 *__restrict__ words /* [.,4] */,
+                                                             const int64_t *__restrict__ index, uint4 *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    int64_t j = t >> 5;
+    if (j >= n) return;
+    u32 chunk = (u32)t & 31;
+    int64_t src = index ? index[j] : j;
+    u32 byte = reinterpret_cast<const uint8_t *>(words + src * 4)[chunk];
+    uint4 v;
+    v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
+    v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
+    v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
+    v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
+    out[j * 32 + chunk] = v;
+}
+
+// ---------------------------------------------------------------------------
 // Learner side of the policy step: the clipped-surrogate policy-gradient loss
 // over the LEGAL cards, forward and gradient in one pass over the head outputs.  Replaces ~40
 // framework elementwise kernels per minibatch (bit-expand of the mask, masked_fill, log_softmax,
@@ -1518,6 +1540,16 @@ int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void 
                        groups, par, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
                        action_out, logp_out, value_out, (ulonglong2 *)feature_words_out, reward_out, done_out, trick_out,
                        (u64 *)obs_out, e->s01, e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_expand_features(tarok_env *e, int64_t n_samples, const uint64_t *feature_words, const int64_t *index,
+                          void *features_out, void *stream) {
+    if (!e || n_samples <= 0 || !feature_words || !features_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_expand_features, grid_for(n_samples * 32), dim3(TK_BLOCK), 0, (hipStream_t)stream, n_samples,
+                       (const u64 *)feature_words, index, (uint4 *)features_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

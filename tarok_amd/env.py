@@ -320,6 +320,18 @@ class TarokVecEnv:
             terms = part.sum(0)[:3] * inv
         return terms, dout
 
+    def gather_features(self, feature_words, index=None, out=None):
+        """tarok_expand_features: [M,4] int64 feature words (+ optional int64 sample index [B]) ->
+        [B,256] bf16 network input, gather and bit expansion in one kernel."""
+        fw = feature_words.contiguous()
+        B = fw.shape[0] if index is None else index.shape[0]
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((B, 256), dtype=torch.bfloat16, device=self.device)
+            idx = None if index is None else index.to(torch.int64).contiguous()
+            _native.check(self.L.tarok_expand_features(self._h, int(B), self._p(fw), self._p(idx), self._p(out), self._stream()))
+        return out
+
     @staticmethod
     def expand_feature_words(words, dtype=torch.bfloat16):
         """[..., 4] int64 feature words (tarok_policy_mlp feature_words_out) -> [..., 256] 0/1 features."""

@@ -275,7 +275,7 @@ class SelfPlay:
         for _ in range(epochs):
             perm = torch.randperm(T * n, device=self.device, generator=self.gen)
             for idx in perm.chunk(minibatches):
-                x = self.env.expand_feature_words(obs[idx]) if self.fused else obs[idx]
+                x = self.env.gather_features(obs, idx) if self.fused else obs[idx]
                 w = m[idx]
                 a = adv[idx]
                 if self.fused_loss:

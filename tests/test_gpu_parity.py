@@ -813,6 +813,9 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
     ref_feat = env.observe()
     assert (feat == ref_feat).all().item()
     assert (env.expand_feature_words(fw) == ref_feat).all().item()      # the 32-byte form of the same features
+    idx = torch.randperm(n, device="cuda")[:7777]
+    assert (env.gather_features(fw, idx) == ref_feat[idx]).all().item()    # gather + expansion kernel
+    assert (env.gather_features(fw) == ref_feat).all().item()
     x = ref_feat.float()
     h = torch.relu(x @ w[0].float().T + w[1]).to(torch.bfloat16).float()
     h = torch.relu(h @ w[2].float().T + w[3]).to(torch.bfloat16).float()
