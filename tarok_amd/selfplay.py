@@ -34,19 +34,27 @@ class _LinearSplitK(torch.autograd.Function):
     (torch.bmm) it is S x 16 tiles; the partials are summed in f32."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, relu):
         cd = torch.bfloat16 if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
         with torch.autocast(x.device.type, enabled=False):
-            xq, wq = x.to(cd), w.to(cd)
-            ctx.save_for_backward(xq, wq)
+            xq, wq, bq = x.to(cd), w.to(cd), b.to(cd)
+            if relu and x.is_cuda:
+                y = torch._addmm_activation(bq, xq, wq.t())      # bias + ReLU in the GEMM's epilogue
+            else:
+                y = F.linear(xq, wq, bq)
+                if relu:
+                    y = F.relu(y)
+            ctx.save_for_backward(xq, wq, y if relu else None)
             ctx.out_dtypes = (x.dtype, w.dtype, b.dtype)
-            return F.linear(xq, wq, b.to(cd))
+            return y
 
     @staticmethod
     def backward(ctx, gy):
-        xq, wq = ctx.saved_tensors
+        xq, wq, y = ctx.saved_tensors
         dx, dw, db = ctx.out_dtypes
         gy = gy.contiguous()
+        if y is not None:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)     # ReLU'
         gx = (gy @ wq).to(dx) if ctx.needs_input_grad[0] else None
         B = xq.shape[0]
         S = next((s for s in (32, 24, 16, 12, 8, 4, 2) if B % s == 0 and B // s >= 512), 1)      # S x 16 tiles >= 256 CUs
@@ -54,7 +62,7 @@ class _LinearSplitK(torch.autograd.Function):
             gw = torch.bmm(gy.view(S, B // S, -1).transpose(1, 2), xq.view(S, B // S, -1)).sum(0, dtype=torch.float32)
         else:
             gw = (gy.t() @ xq).float()
-        return gx, gw.to(dw), gy.sum(0, dtype=torch.float32).to(db)
+        return gx, gw.to(dw), gy.sum(0, dtype=torch.float32).to(db), None
 
 
 class PolicyNet(nn.Module):
@@ -70,12 +78,12 @@ class PolicyNet(nn.Module):
     def forward_raw(self, x):
         """all 64 head outputs [N,64]"""
         if x.dim() == 2 and x.shape[0] >= 16384 and torch.is_grad_enabled():    # a training minibatch
-            lin = lambda m, t: _LinearSplitK.apply(t, m.weight, m.bias)
-        else:
-            lin = lambda m, t: m(t)
-        h = F.relu(lin(self.fc1, x))
-        h = F.relu(lin(self.fc2, h))
-        return lin(self.head, h)
+            h = _LinearSplitK.apply(x, self.fc1.weight, self.fc1.bias, True)
+            h = _LinearSplitK.apply(h, self.fc2.weight, self.fc2.bias, True)
+            return _LinearSplitK.apply(h, self.head.weight, self.head.bias, False)
+        h = F.relu(self.fc1(x))
+        h = F.relu(self.fc2(h))
+        return self.head(h)
 
     def forward(self, x):
         out = self.forward_raw(x)
