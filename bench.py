@@ -3,31 +3,46 @@
 (BASELINE.json metric; workload = configs[2]: mixed Klop/Berac/Navadna contracts,
 uniform-random policy, synthetic deals).
 
-    python bench.py --gpus 1 --steps 4800 --warmup 480
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one lock-step of every game = one card played in each of the 65,536
-games of a rank (Tarok.py:48-56): legal mask of the seat to move, a uniform random
-legal card (the Bot policy, Igralec.py:158-159), the card applied, trick resolution
-and scoring, finished games replaced at once (auto-reset: every slot is live in
-every step), next observation written.  One kernel launch plays TWELVE TRICKS (48 such
-steps; one trick = one pass of the reference's krog generator) with the state held in
-registers in between and every per-card output (action, observation word, done,
-scores) written to HBM; state is resident in HBM between launches.  One trick per
-launch (--cards-per-launch 4) is reported beside it, as are  value = games x steps x ranks / max-over-ranks time.
-one card per launch and the two-kernel external-policy path.  Weak scaling: each rank owns its own 65,536 games
-(global game indices rank*65536...), no collective in the env path.
+One bench "step" = one pass of the hot path over the batch = ONE launch of
+tarok_krog_random: `--cards-per-launch` (default 48 = twelve tricks) lock-steps of every
+one of a rank's 65,536 games.  One lock-step = one card played in each game
+(Tarok.py:48-56): legal mask of the seat to move, a uniform random legal card (the Bot
+policy, Igralec.py:158-159), the card applied, trick resolution and scoring, finished
+games replaced at once (auto-reset: every slot is live in every lock-step), next
+observation written.  The state stays in registers for the cards of one launch and is
+resident in HBM between launches; every per-card output (action, observation word, done,
+scores) is written to HBM.
+    value = games x cards per launch x steps x ranks / max-over-ranks time   [env steps/s]
+Exactly --steps launches are timed (never fewer than one; --warmup is raised to one whole
+graph so that the capture is untimed: `warmup` reports what ran).  Weak scaling: each rank
+owns its own 65,536 games (global game indices rank*65536...), no collective in the env path.
 
 Extra objects on the JSON line:
-  roofline      the step kernel against HBM peak: algorithmic 54 B/step
-                x 65,536 games per launch / launch duration, measured with HIP events
-                on the launch stream around the timed region.
-  cpu_baseline  the CPU oracle (oracle/, a C port of the reference rules — test
-                infrastructure, used here only as the reported baseline) on the host
-                cores, bounded sample of the same workload.  rank 0, N=1 only.
+  roofline           the dominant kernel (k_play<true>) against HBM peak.  `achieved` =
+                     HBM bytes per launch / launch duration (HIP events on the launch stream
+                     over the timed region / launches).  For launches of several cards the
+                     bytes are the MEASURED ones (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of
+                     this command, profiles/): such a launch keeps the state in registers and
+                     does not move the 54 algorithmic B/step of SURVEY 8d, which are reported
+                     beside it as `algorithmic` (that figure is not a bound: it can exceed 1).
+  roofline_step_api  the reset()/step()/legal_actions() surface an external policy drives
+                     (tarok_policy_random + tarok_step, one card per launch), where 54 B/step
+                     IS the right accounting.
+  issue_roofline     what really bounds k_play<true>: vector-instruction issue (instruction
+                     count per step from the committed SQ counters x the measured issue cost
+                     per instruction from tools/valu_issue.hip).
+  cpu_baseline       the CPU oracle (oracle/, a C port of the reference rules — test
+                     infrastructure, used here only as the reported baseline) on the host
+                     cores, bounded sample of the same workload.  rank 0, N=1 only.
+Objects read from profiles/ carry the hash of the kernel sources they were measured on and
+`stale: true` when it differs from the running library's.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,6 +54,75 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_STEP = 54
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
+PROFILE_TAG = "r02"             # profiles/<tag>_* are the files read below
+SIDE_LOCK_STEPS_CAP = 9600      # side legs: at most this many lock-steps per timed region
+
+
+def graph_size(passes, limit):
+    """Launches per hipGraph for a region of `passes` launches, at most `limit`: the largest divisor of
+    `passes` (no eager remainder) unless that makes the graphs short (< 8 launches); then `limit` with
+    the remainder launched eagerly."""
+    limit = max(1, min(limit, passes))
+    best = max(d for d in range(1, limit + 1) if passes % d == 0)
+    return best if best >= min(8, limit) else limit
+
+
+def plan_region(passes, cards, graph_lock_steps=1536, launches_per_graph=None):
+    """How `passes` launches of `cards` lock-steps each are enqueued (pure; tests/test_bench_plan.py).
+    launches_per_graph: use this graph size (a warm-up that must capture the timed region's graph).
+
+    cards: 0 = tarok_policy_random + tarok_step (two kernels per lock-step), 1 = tarok_step_random,
+    >= 2 = tarok_krog_random(cards).  Returns the arguments of tarok_run_random and what it will do:
+    replays of one hipGraph of `per_graph` launches, then `eager` single launches.  Never zero launches."""
+    passes = max(1, int(passes))
+    unit = max(1, int(cards))                         # lock-steps per launch
+    per_graph = graph_size(passes, max(1, int(graph_lock_steps) // unit)) if graph_lock_steps > 0 else 0
+    if launches_per_graph is not None and graph_lock_steps > 0:
+        per_graph = int(launches_per_graph)
+        passes = max(passes, per_graph)                 # at least one whole graph
+    replays = passes // per_graph if per_graph else 0
+    eager = passes - replays * per_graph
+    return {"cards": int(cards), "lock_steps_per_launch": unit, "launches": passes, "lock_steps": passes * unit,
+            "graph_chunk": per_graph * unit, "launches_per_graph": per_graph, "graph_replays": replays,
+            "eager_launches": eager, "kernels_per_launch": 2 if cards == 0 else 1}
+
+
+def describe_mode(plan):
+    c = plan["cards"]
+    how = ("%d replay(s) of a hipGraph of %d launch(es)" % (plan["graph_replays"], plan["launches_per_graph"])
+           if plan["graph_replays"] else "eager launches")
+    if plan["eager_launches"]:
+        how += " + %d eager launch(es)" % plan["eager_launches"]
+    if c >= 2:
+        return ("tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's krog); "
+                "action, observation, done, scores written to HBM for every card; %s; finished games' successors (dealt "
+                "seven games ahead by the refill workgroups of the previous launch) are swapped in inside the same launch"
+                % (c, how))
+    if c == 1:
+        return "tarok_step_random: one card of every game per launch, policy in-kernel; " + how
+    return "tarok_policy_random + tarok_step: two launches per lock-step (what an external policy drives); " + how
+
+
+def kernel_src_sha():
+    """Hash of the sources libtarokenv.so is built from: what a profile was measured on."""
+    from tarok_amd import _native
+    h = hashlib.sha256()
+    for p in _native.DEPS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name, sha):
+    """profiles/<name> -> (dict or None, provenance dict with `stale`)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, {"source": None}
+    with open(path) as f:
+        obj = json.load(f)
+    meas = obj.get("kernel_src_sha")
+    return obj, {"source": "profiles/" + name, "measured_on_kernel_src_sha": meas, "running_kernel_src_sha": sha,
+                 "stale": meas != sha}
 
 
 def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
@@ -79,19 +163,22 @@ def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9600, help="timed lock-steps (default ~260 games per slot)")
-    ap.add_argument("--warmup", type=int, default=960, help="untimed lock-steps (default ~26 games per slot)")
-    ap.add_argument("--repeats", type=int, default=5, help="extra timed regions of --steps steps, reported as a spread")
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed passes of the hot path = kernel launches of --cards-per-launch lock-steps each "
+                         "(default 200 x 48 = 9,600 lock-steps, ~260 games per slot)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed passes (raised to one whole graph)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps passes in all, reported as a spread")
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--graph-chunk", type=int, default=192, help="steps per replayed hipGraph (0 = eager)")
-    ap.add_argument("--prefetch-every", type=int, default=0,
-                    help="extra synchronous tarok_prefetch every k steps (0: none; the step launches refill the buffers themselves)")
+    ap.add_argument("--graph-chunk", type=int, default=1536, help="at most this many lock-steps per replayed hipGraph (0 = eager)")
     ap.add_argument("--cards-per-launch", type=int, default=48,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
                          "48 = twelve tricks; 1 = one card per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the fused-kernel side measurements")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
+    ap.add_argument("--strict", action="store_true", help="exit 1 (after printing the line) when a side leg failed")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or not (1 <= args.cards_per_launch <= 48):
+        ap.error("--steps >= 1, --warmup >= 0, 1 <= --cards-per-launch <= 48")
 
     import torch
     from tarok_amd import TarokVecEnv, karte as K, sharding
@@ -110,150 +197,158 @@ def main():
     n = args.games
     offset, _ = sharding.weak_shard(n, rank)
     env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
+    sha = kernel_src_sha()
+    errors = []
 
-    cards = max(1, args.cards_per_launch)
-    pf = max(0, args.prefetch_every)
-    pf = (pf + cards - 1) // cards * cards          # a prefetch period is a whole number of launches
-    # a graph chunk never longer than the timed region, holding an even number of launches
-    q = max(pf, 2 * cards)
-    chunk = min(args.graph_chunk, (args.steps // q) * q) // q * q if args.graph_chunk > 0 else 0
+    def run(plan):
+        env.run_random(plan["lock_steps"], cards_per_launch=plan["cards"], graph_chunk=plan["graph_chunk"], auto_reset=True)
 
-    def run(steps, mode):
-        """mode: 0 = policy kernel + step kernel, 1 = one card per launch, >= 2 = that many cards per launch"""
-        unit = max(1, mode)
-        main = steps // unit * unit
-        if main:
-            env.run_random(main, cards_per_launch=mode, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
-        if steps - main:                                  # K not a multiple of the cards per launch: finish card by card
-            env.run_random(steps - main, cards_per_launch=1, graph_chunk=0, auto_reset=True, prefetch_every=0)
-
-    def timed(steps, mode):
+    def timed(plan, events=None):
+        """barrier + synchronize, the plan's launches, synchronize + barrier; MAX over ranks of the wall time.
+        events: (ev0, ev1, stream) recorded on the launch stream around the same launches."""
         sharding.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        run(steps, mode)
+        if events:
+            events[0].record(events[2])
+        run(plan)
+        if events:
+            events[1].record(events[2])
         torch.cuda.synchronize(dev)
         sharding.barrier()
         dt = time.perf_counter() - t0
         return sharding.max_over_ranks([dt])[0]
 
-    # ---- headline: one launch of tarok_krog_random per `cards` lock-steps: per card legal mask ->
-    # uniform random legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap ->
-    # next observation; state read once and written once per launch, every per-card output
-    # (action, observation word, done, scores) written to HBM.  Replayed as a hipGraph of
-    # `graph_chunk` steps; tarok_prefetch every `prefetch_every` steps deals the finished slots'
-    # next games.
+    def leg(cards, passes):
+        """A side leg: reset, warm up (graph capture untimed), one timed region.  -> (plan, seconds)"""
+        plan = plan_region(passes, cards, args.graph_chunk)
+        env.reset(episode=0)
+        run(plan_region(min(passes, 2 * plan["launches_per_graph"]), cards, args.graph_chunk, plan["launches_per_graph"]))
+        return plan, timed(plan)
+
+    # ---- headline: --steps launches of tarok_krog_random(cards); per card: legal mask -> uniform random
+    # legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap -> next observation
+    cards = args.cards_per_launch
+    plan = plan_region(args.steps, cards, args.graph_chunk)
+    wplan = plan_region(args.warmup, cards, args.graph_chunk, plan["launches_per_graph"])
     env.reset(episode=0)
-    run(max(args.warmup, chunk), cards)          # at least one whole chunk: the graph is captured here, untimed
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run(wplan)                                # the graph is captured here, untimed
     stream = torch.cuda.current_stream(dev)
-    sharding.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(args.steps, cards)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    sharding.barrier()
-    dt_local = time.perf_counter() - t0
-    dt = sharding.max_over_ranks([dt_local])[0]
-    ev_ms = ev0.elapsed_time(ev1)
-    total_steps = n * args.steps * world_size
-    value = total_steps / dt
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), stream)
+    dt = timed(plan, ev)
+    ev_ms = ev[0].elapsed_time(ev[1])
+    env_steps = n * plan["lock_steps"] * world_size
+    value = env_steps / dt
     # BASELINE.md: 5 repeats, median (min-max).  `value` stays the first region (the contract's one).
-    spread = [value] + [total_steps / timed(args.steps, cards) for _ in range(max(0, args.repeats - 1))]
+    spread = [value] + [env_steps / timed(plan) for _ in range(max(0, args.repeats - 1))]
     ep, ss = env.counters()
 
     out = {
         "metric": "env steps/sec at 65,536 parallel 4-player games; 1/2/4/8 MI355X",
-        "value": value, "unit": "env steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "env steps/s", "n_gpus": world_size, "steps": plan["launches"], "warmup": wplan["launches"],
+        "steps_requested": args.steps, "warmup_requested": args.warmup,
+        "ms_per_step": dt / plan["launches"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
+        "step_definition": "one pass of the hot path over the batch = one kernel launch = %d lock-step(s) (cards) of each of "
+                           "the %d games of a rank = %d env steps per rank" % (plan["lock_steps_per_launch"], n,
+                                                                            n * plan["lock_steps_per_launch"]),
+        "lock_steps_timed": plan["lock_steps"], "us_per_lock_step": dt / plan["lock_steps"] * 1e6,
+        "timed_region": {"wall_ms_max_over_ranks": dt * 1e3, "hip_event_ms_rank0": ev_ms,
+                         "note": "value uses the wall time (barrier + synchronize on both sides); the HIP events bracket the "
+                                 "same launches on the launch stream"},
         "config": {"workload": "configs[2]: %d parallel envs per GPU, mixed Klop/Berac/Navadna contracts "
                                "(1/3 Klop, 1/3 Berac incl. 1/2 open, 1/3 Navadna+Solo over 7 types), uniform random policy, "
                                "auto-reset (every slot live in every step)" % n,
-                   "games_per_gpu": n,
-                   "mode": "tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's "
-                           "krog); action, observation, done, scores written to HBM for every card; hipGraph of %d steps; "
-                           "finished games' successors (dealt seven games ahead by the refill workgroups of the previous "
-                           "launch) are swapped in inside the same launch" % (cards, chunk),
-                   "cards_per_launch": cards,
+                   "games_per_gpu": n, "mode": describe_mode(plan), "cards_per_launch": cards, "launch_plan": plan,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
         "repeats": {"n": len(spread), "median": sorted(spread)[len(spread) // 2], "min": min(spread), "max": max(spread)},
+        "kernel_src_sha": sha,
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_play<true>): HIP events on the launch stream around
-        # the timed region above; launch duration = region time / launches (every launch gap is
-        # charged to the kernel -> a lower bound on its bandwidth).  One launch processes n x cards
-        # steps, each 54 algorithmic bytes (SURVEY 8d).
-        launches = args.steps // cards
-        k_us = ev_ms * 1e3 / launches
-        algo_bytes = ALGO_BYTES_PER_STEP * n * cards
-        achieved = algo_bytes / (k_us * 1e-6) / 1e9
-        # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this same
-        # command (counters cannot be read from inside the process): FETCH_SIZE x2 + WRITE_SIZE
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_65536.json")
-        if n == 65536 and os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("k_play_traffic_bytes_per_launch_cards%d" % cards)
-            traffic_src = "profiles/r01_pmc_fetch_write_65536.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "k_play<true> (%s)" % ("tarok_krog_random" if cards > 1 else "tarok_step_random"),
-                           "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": algo_bytes, "launch_us": k_us, "steps_per_launch": n * cards,
-                           "note": "54 B/step (SURVEY 8d) x %d games x %d cards per launch / (HIP-event time of the timed "
-                                   "region / launches); at this N the per-GPU state (2 MB) is cache resident and there is one "
-                                   "wave per SIMD: the launch is bound by that wave's instruction issue, see DESIGN.md for "
-                                   "the N-sweep and the VALU-issue ceiling"
-                                   % (n, cards)}
+        # ---- roofline of the dominant kernel (k_play<true>): HIP events on the launch stream around the
+        # timed region; launch duration = region time / launches (every launch gap is charged to the
+        # kernel -> a lower bound on its bandwidth).
+        k_us = ev_ms * 1e3 / plan["launches"]
+        algo_bytes = ALGO_BYTES_PER_STEP * n * plan["lock_steps_per_launch"]
+        algo = {"bytes_per_step": ALGO_BYTES_PER_STEP, "bytes_per_launch": algo_bytes,
+                "achieved": algo_bytes / (k_us * 1e-6) / 1e9, "unit": "GB/s"}
+        algo["frac"] = algo["achieved"] / HBM_PEAK_GBS
+        # HBM-side bytes per launch: rocprofv3 PMC passes of this same command (counters cannot be read
+        # from inside the process): FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py
+        pmc, prov = load_profile("%s_pmc_fetch_write_%d.json" % (PROFILE_TAG, n), sha)
+        traffic = pmc.get("k_play_traffic_bytes_per_launch_cards%d" % cards) if pmc else None
+        roof = {"bound": "hbm", "kernel": "k_play<true> (%s)" % ("tarok_krog_random" if cards > 1 else "tarok_step_random"),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_us": k_us, "steps_per_launch": n * plan["lock_steps_per_launch"],
+                "traffic": traffic, "traffic_provenance": prov, "algorithmic": algo}
+        if cards > 1 and traffic:
+            roof.update(accounting="measured HBM bytes (PMC FETCH_SIZE x2 + WRITE_SIZE per launch)",
+                        achieved=traffic / (k_us * 1e-6) / 1e9)
+            algo["note"] = ("SURVEY 8d's 54 B/step prices a kernel that streams the state once per card; a %d-card launch keeps it "
+                            "in registers, so this figure is NOT a bound for it (it exceeds 1 at 16 M games)" % cards)
+        else:
+            roof.update(accounting="algorithmic 54 B/step (SURVEY 8d)" + ("" if cards == 1 else
+                                   "; no PMC profile of this launch shape is committed, see `algorithmic.note`"),
+                        achieved=algo["achieved"])
+            if cards > 1:
+                algo["note"] = "the state stays in registers for the cards of a launch: real traffic is lower than this figure"
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["note"] = ("at %d games the per-GPU state (%.0f MB with the next-game lines) is cache resident and there are only "
+                        "%d play waves for 1,024 SIMDs: the launch is bound by instruction issue, not by HBM (issue_roofline; "
+                        "DESIGN.md has the N sweep)" % (n, n * 520 / 1e6, (n + 63) // 64))
+        out["roofline"] = roof
 
-    if rank == 0:
-        # ---- what actually bounds the kernel (DESIGN.md §5): the VALU instruction count per step,
-        # from the committed SQ counter passes of this kernel (tools/sq_counters.sh: 4 M games, where
-        # the vector ALUs are busy ~96 % of the launch).  Ceiling = SIMDs x clock / 4 cycles per
-        # wave64 instruction x 64 lanes / instructions per step; reported beside the HBM roofline.
-        sq = os.path.join(ROOT, "profiles", "r01_sq_counters_4194304.json")
-        if os.path.exists(sq):
-            with open(sq) as f:
-                c = json.load(f)
-            if c.get("cards_per_launch") == cards and "SQ_INSTS_VALU" in c:
-                waves = c["games"] / 64.0 * c["cards_per_launch"]
-                per_step = c["SQ_INSTS_VALU"]["mean"] / waves
-                ceiling = 1024 * 2.3e9 / 4.0 * 64.0 / per_step
-                out["issue_roofline"] = {"bound": "valu", "valu_instructions_per_step": per_step,
-                                         "all_instructions_per_step": (c["SQ_INSTS_VALU"]["mean"] + c["SQ_INSTS_SALU"]["mean"] +
-                                                                       c["SQ_INSTS_BRANCH"]["mean"] + c["SQ_INSTS_VMEM_WR"]["mean"] +
-                                                                       c["SQ_INSTS_VMEM_RD"]["mean"]) / waves,
-                                         "valu_busy_at_4M_games": c["SQ_ACTIVE_INST_VALU"]["mean"] * 4.0 / (1024 * c["GRBM_GUI_ACTIVE"]["mean"] / 8.0),
-                                         "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
-                                         "source": "profiles/r01_sq_counters_4194304.json",
-                                         "note": "1024 SIMDs x 2.3 GHz / 4 cycles x 64 lanes / VALU instructions per step"}
+        # ---- what actually bounds the kernel (DESIGN.md §5): vector-instruction issue.  VALU instructions
+        # per step from the committed SQ counter passes (tools/sq_counters.sh), cycles per VALU instruction
+        # from the issue microbenchmark (tools/valu_issue.hip -> profiles/<tag>_valu_issue.json).
+        sq, sq_prov = load_profile("%s_sq_counters.json" % PROFILE_TAG, sha)
+        vi, _ = load_profile("%s_valu_issue.json" % PROFILE_TAG, sha)
+        if sq and vi and sq.get("cards_per_launch") == cards and "SQ_INSTS_VALU" in sq:
+            waves = sq["games"] / 64.0 * sq["cards_per_launch"]
+            per_step = sq["SQ_INSTS_VALU"]["mean"] / waves
+            cyc = vi["k_play_mix_cycles_per_valu"]            # measured, weighted by k_play's instruction mix
+            clock = vi.get("clock_hz", 2.4e9)
+            ceiling = 1024 * clock / cyc * 64.0 / per_step
+            out["issue_roofline"] = {"bound": "valu issue", "valu_instructions_per_step": per_step,
+                                     "cycles_per_valu_instruction": cyc, "clock_hz": clock,
+                                     "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
+                                     "provenance": sq_prov, "issue_cost_source": "profiles/%s_valu_issue.json" % PROFILE_TAG,
+                                     "note": "1024 SIMDs x clock / measured cycles per wave64 VALU instruction x 64 lanes / "
+                                             "VALU instructions per step"}
 
     if not args.no_extras:
-        # ---- side measurements (not `value`)
-        # (a) the two-kernel C-ABI path: tarok_policy_random writes the action array, tarok_step consumes it
-        env.reset(episode=0)
-        run(max(args.warmup, chunk), 0)
-        dta = timed(args.steps, 0)
-        out["api_two_kernel"] = {"value": total_steps / dta, "unit": "env steps/s", "ms_per_step": dta / args.steps * 1e3,
+        # ---- side measurements (not `value`); lock-steps per region = the headline's, capped
+        side_steps = min(plan["lock_steps"], SIDE_LOCK_STEPS_CAP)
+        # (a) the C-ABI surface an external policy drives: tarok_policy_random writes the action array,
+        # tarok_step consumes it — one card per launch, state through HBM every card: 54 B/step is the
+        # right accounting here (SURVEY 8d)
+        p0, dta = leg(0, side_steps)
+        s0 = n * p0["lock_steps"] * world_size
+        us0 = dta / p0["lock_steps"] * 1e6
+        out["api_two_kernel"] = {"value": s0 / dta, "unit": "env steps/s", "us_per_lock_step": us0, "launch_plan": p0,
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
-        # (a'') one trick per launch (tarok_krog_random, 4 cards)
+        if rank == 0:
+            ach = ALGO_BYTES_PER_STEP * n / (us0 * 1e-6) / 1e9
+            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_play<false> (tarok_step) behind k_policy (tarok_policy_random)",
+                                        "accounting": "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step" % n,
+                                        "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                        "us_per_lock_step": us0, "traffic": None,
+                                        "note": "wall time of the timed region / lock-steps: both launches and their gaps are "
+                                                "charged to the step; at %d games (state cache resident, one wave per SIMD) a "
+                                                "launch is latency bound — see profiles/ for the N sweep of this path" % n}
+        # (a') one trick per launch (tarok_krog_random, 4 cards)
         if cards != 4:
-            env.reset(episode=0)
-            run(max(args.warmup, chunk), 4)
-            dt4 = timed(args.steps, 4)
-            out["one_trick_per_launch"] = {"value": total_steps / dt4, "unit": "env steps/s", "ms_per_step": dt4 / args.steps * 1e3,
+            p4, dt4 = leg(4, max(1, side_steps // 4))
+            out["one_trick_per_launch"] = {"value": n * p4["lock_steps"] * world_size / dt4, "unit": "env steps/s",
+                                           "us_per_lock_step": dt4 / p4["lock_steps"] * 1e6, "launch_plan": p4,
                                            "note": "tarok_krog_random with 4 cards: 1 launch per trick (one pass of the reference's krog)"}
-        # (a') one card per launch with the policy in-kernel (tarok_step_random)
-        env.reset(episode=0)
-        run(max(args.warmup, chunk), 1)
-        dt1 = timed(args.steps, 1)
-        out["one_card_per_launch"] = {"value": total_steps / dt1, "unit": "env steps/s", "ms_per_step": dt1 / args.steps * 1e3,
-                                      "note": "tarok_step_random: 1 launch per lock-step"}
+        # (a'') one card per launch with the policy in-kernel (tarok_step_random)
+        if cards != 1:
+            p1, dt1 = leg(1, side_steps)
+            out["one_card_per_launch"] = {"value": n * p1["lock_steps"] * world_size / dt1, "unit": "env steps/s",
+                                          "us_per_lock_step": dt1 / p1["lock_steps"] * 1e6, "launch_plan": p1,
+                                          "note": "tarok_step_random: 1 launch per lock-step"}
         # (b) whole games per launch, state in registers
         sharding.barrier()
         torch.cuda.synchronize(dev)
@@ -272,34 +367,43 @@ def main():
                                 "note": "tarok_rollout_random: whole games in registers, one launch per %d games; "
                                         "no per-step HBM state, so no HBM fraction is claimed for it" % n}
 
-        # (c) BASELINE configs 4-5: self-play with a small bf16 MLP policy (tarok_observe -> net ->
-        # masked sample -> tarok_step), PPO-style update, gradient all-reduce over RCCL when N > 1.
-        # Build-owned (the reference has no PPO): reported, never part of `value`.
+        # (c) BASELINE configs 4-5: self-play with a small bf16 MLP policy (features -> MLP -> masked sample
+        # -> env step in one launch), PPO-style update, gradient all-reduce over RCCL when N > 1.
+        # Build-owned (the reference has no PPO): reported, never part of `value`.  A failure here is
+        # printed on stderr and listed in `side_leg_errors` (and fails the run under --strict); the same
+        # configuration at this size is a -m gpu test (test_selfplay_65536_envs_vs_oracle_replay).
         try:
             from tarok_amd import selfplay
+            env.reset(episode=0)
             sp = selfplay.SelfPlay(env, hidden=256, seed=0)
             sp.iterate(T=48, epochs=1, minibatches=8)
             st = sp.iterate(T=48, epochs=1, minibatches=8)
             tro = sharding.max_over_ranks([st["rollout_s"], st["update_s"]])
-            out["selfplay_ppo"] = {"rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_ms_per_step": tro[0] / 48 * 1e3,
+            out["selfplay_ppo"] = {"rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_us_per_lock_step": tro[0] / 48 * 1e6,
                                    "update_ms": tro[1] * 1e3, "minibatches": 8, "allreduce_bytes_per_minibatch": st["allreduce_bytes"],
                                    "policy": "MLP 256-256-256-64 (54 card logits + value), bf16 MFMA", "loss": st["loss"],
                                    "note": "env steps/s including the policy: per lock-step one tarok_policy_step launch "
                                            "(features -> MLP -> masked sample -> env step), graph replayed; update = PPO-style, "
                                            "tarok_ppo_loss + torch GEMMs"}
             del sp
-        except Exception as ex:                      # never let the side leg break the bench line
+        except Exception as ex:
             out["selfplay_ppo"] = {"error": repr(ex)}
+            errors.append("selfplay_ppo: " + repr(ex))
+            print("bench.py: the self-play side leg FAILED: %r" % (ex,), file=sys.stderr)
 
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(1 << 20, K.MIX_ALL)
+    out["side_leg_errors"] = errors
 
     env.close()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world_size > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if errors and args.strict:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

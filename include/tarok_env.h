@@ -172,7 +172,9 @@ int tarok_krog_random(tarok_env *env, int cards, int64_t stride, uint8_t *action
  * c >= 2: tarok_krog_random(c) — n_steps, graph_chunk and prefetch_every must be multiples of c
  * and the buffers hold c rows of N (action [c,N], reward_out [c,N,4], done_out [c,N], obs_out [c,N]).
  * prefetch_every = k > 0: an extra tarok_prefetch after every k-th step (graph_chunk must be a
- * multiple of k); normally 0.  graph_chunk must hold an even number of launches.
+ * multiple of k); normally 0.  Any number of launches per graph: the refill-list parity lives in
+ * device memory and is advanced by the launches themselves, so graph replays (this library's or a
+ * caller's own capture of tarok_* calls) and eager launches may be mixed in any order.
  * Buffers otherwise as in tarok_step (action [N] u8 scratch is required for cards_per_launch = 0). */
 int tarok_run_random(tarok_env *env, int64_t n_steps, int cards_per_launch, int graph_chunk,
                      int prefetch_every, uint8_t *action, int16_t *reward_out, uint8_t *done_out,

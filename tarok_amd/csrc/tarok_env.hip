@@ -13,10 +13,12 @@
 // (sorting-network deals on dense lanes) while its own play workgroups run — the ~5 us of deal
 // latency overlaps the next launch instead of following this one.  Seven games ahead let a launch
 // play up to twelve tricks (the shortest game, a Berac lost on trick 1, is 4 cards) practically
-// without ever waiting for a deal.  Lists are double-buffered by launch parity; a line is valid
-// iff its episode tag matches and it is not being re-dealt right now (`cprev` in the slot's
-// state), and a slot that ever runs out of usable lines just deals the game itself,
-// wave-cooperatively (ballot/readlane), same result.
+// without ever waiting for a deal.  Lists are double-buffered by launch parity — the low bit of a
+// launch epoch kept in DEVICE memory, advanced by the last workgroup of every step launch to finish
+// (launch_done), so eager launches and replays of captured graphs (the library's own or a caller's,
+// e.g. torch.cuda.graph) mix freely and in any number.  A line is valid iff its episode tag matches
+// and it is not being re-dealt right now (`cprev` in the slot's state), and a slot that ever runs
+// out of usable lines just deals the game itself, wave-cooperatively (ballot/readlane), same result.
 #include "tarok_device.h"
 
 #include <hip/hip_runtime.h>
@@ -42,15 +44,23 @@
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 
-// Per-slot side record, four 64-byte lines.  Line b holds the dealt-ahead game whose episode
-// number is b mod 4: its packed pairs, its RNG key and the episode number it is (the validity tag,
-// written last).
+// Per-slot side record: TK_AHEAD (seven) 64-byte next-game lines.  Line b holds the dealt-ahead
+// game whose episode number is b mod TK_AHEAD: its packed pairs, its RNG key and the episode number
+// it is (the validity tag).  A 64-byte AuxLine is HALF an L2 line (128 B on MI355X), and a slot's
+// 448-byte record shares its first / last L2 line with a neighbouring slot.  That is safe because
+// (i) only refill workgroups ever write these records — play workgroups read them and write
+// nothing here (their Counters / state / gkey / refill lists live in lines of their own, see
+// Counters below), (ii) all lines of one play group's 256 slots (a 112 KiB, 128-byte aligned
+// range) are re-dealt by ONE refill workgroup per launch, so no L2 line is written by two
+// workgroups (two XCDs) within a launch, and (iii) a reader never trusts a line whose episode tag
+// does not match or that `cprev` says is being re-dealt right now.
 struct __attribute__((aligned(64))) AuxLine {
     ulonglong2 n01, n23; u64 nkey; u32 nep;
     u32 pad[5];
 };
 struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
-static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 64 * TK_AHEAD, "one cache line per next-game line");
+static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 64 * TK_AHEAD, "64 bytes per next-game line");
+static_assert((256 * sizeof(Aux)) % 128 == 0, "a play group's next-game lines end on an L2 line boundary");
 static_assert(TK_AHEAD >= 2 && TK_AHEAD <= 7, "epar / cprev are 3-bit fields");
 // What a finishing game always touches: the slot's episode number and its summed scores.  Kept
 // apart from the next-game lines: those are written by refill workgroups, these by the slot's own
@@ -76,13 +86,14 @@ struct tarok_env {
     u64 *gkey;               // RNG key of the slot's current game
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
     u32 *rcount;             // [play workgroups][2]
-    uint32_t launch_no;      // play launches enqueued so far (parity selects the list written / worked off)
+    u32 *epoch;              // [0] launch epoch (its low bit = parity of the refill list a launch writes; it works the
+                             // other one off), [32] workgroups of the running launch that are done: two 128-byte lines
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
     hipGraphExec_t gexec;
-    int g_fused, g_chunk, g_flags, g_prefetch, g_par0;
+    int g_fused, g_chunk, g_flags, g_prefetch;
     void *g_action, *g_reward, *g_done, *g_obs;
 };
 
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     if (flags & TAROK_CLEAR_COUNTERS) cnt[i].score_sum = make_int4(0, 0, 0, 0);
 }
 
-// Deal game `episode` of slot j ahead of time into its line (episode & 3).
+// Deal game `episode` of slot j ahead of time into its line (episode mod TK_AHEAD).
 __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t j, u32 episode, u64 seed, u64 offset, int mix) {
     u64 key = game_key(seed, offset + (u64)j, (u64)episode);
     u64 h0, h1, h2, h3, tal;
@@ -259,6 +270,29 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
     u32 a = 255;
     if (m) a = policy_action(gkey[i], (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m);
     action[i] = (uint8_t)a;
+}
+
+// Launch epoch (see the file header).  Every workgroup of a step launch reads it when it starts
+// (its low bit = this launch's list parity); the workgroup that finishes last advances it for the
+// next launch.  Nothing writes the epoch while a workgroup of the launch can still read it: every
+// workgroup's read has completed (the barrier's s_waitcnt) before its own "done" count, and the
+// write follows the last such count.  Agent-scope atomics: the counter is shared by all XCDs.
+// RELAXED on purpose: the ordering needed inside the launch comes from the barrier and from the
+// counter's own modification order, and the next launch sees the new epoch through the kernel
+// boundary; an acquire/release pair here would write back and invalidate the L2 in every
+// workgroup (+11 us per launch when it was tried).
+__device__ __forceinline__ u32 launch_epoch(const u32 *epoch) {
+    return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void launch_done(u32 *epoch, u32 ep) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 old = __hip_atomic_fetch_add(epoch + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(epoch + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(epoch, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // THE step kernel.  One launch plays `cards` cards of every game:
@@ -489,7 +523,7 @@ __device__ __forceinline__ void play_role(
     } else {
         for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, row);
     }
-    // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+4.
+    // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+TK_AHEAD.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
     // a game dealt in place: all of them.
     u32 np = resync ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
@@ -525,17 +559,18 @@ __device__ __forceinline__ void play_role(
 // card loops would otherwise take 131)
 template <bool RANDOM>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 par, u32 fan,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
-    if (blockIdx.x >= play_groups) {
+    u32 ep = launch_epoch(epoch), par = ep & 1u;
+    if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
-        return;
-    }
-    play_role<RANDOM>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in, action_out,
-                      reward, done, trick, obs, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
+    else
+        play_role<RANDOM>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in, action_out,
+                          reward, done, trick, obs, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
+    launch_done(epoch, ep);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1133,7 +1168,7 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
 // kernel's play role on them (threads 0..255; same refill lists, same launch-parity protocol as
 // k_play); the workgroups after the play groups run the refill role.
 __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 par, u32 fan,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,
     const u64 *__restrict__ obs_in, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
@@ -1141,8 +1176,10 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     uint16_t *__restrict__ trick, u64 *__restrict__ obs_out,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
+    u32 ep = launch_epoch(epoch), par = ep & 1u;
     if (blockIdx.x >= play_groups) {
         refill_role(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
+        launch_done(epoch, ep);
         return;
     }
     __shared__ uint8_t act_s[2 * PM_M];
@@ -1152,6 +1189,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     u32 tid = threadIdx.x;
     play_role<false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n, par,
                      nullptr, nullptr, reward, done, trick, obs_out, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
+    launch_done(epoch, ep);
 }
 
 __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
@@ -1282,6 +1320,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 64 * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->epoch, 0, 64 * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
@@ -1305,7 +1345,7 @@ void tarok_destroy(tarok_env *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
-    (void)hipFree(e->rlist); (void)hipFree(e->rcount);
+    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch);
     delete e;
 }
 
@@ -1362,17 +1402,15 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
                                uint8_t *action_out, int16_t *reward, uint8_t *done, uint16_t *trick, uint64_t *obs,
                                int flags, hipStream_t s) {
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
-    u32 par = e->launch_no & 1u;
-    e->launch_no++;
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     if (random)
         hipLaunchKernelGGL(k_play<true>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
                            e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
     else
         hipLaunchKernelGGL(k_play<false>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, par, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
+                           groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
                            e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
 }
 
@@ -1432,7 +1470,6 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
     if (n_steps % unit != 0 || graph_chunk % unit != 0) return TAROK_EINVAL;
     if (prefetch_every % unit != 0) return TAROK_EINVAL;
     if (graph_chunk > 0 && prefetch_every > 0 && graph_chunk % prefetch_every != 0) return TAROK_EINVAL;
-    if (graph_chunk > 0 && ((graph_chunk / unit) & 1)) return TAROK_EINVAL;   // even launch count: parity survives a replay
     if (!(flags & TAROK_AUTO_RESET)) prefetch_every = 0;
     if (cards_per_launch == 0 && !action) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
@@ -1445,26 +1482,20 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
         if (!hit) {
             if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
             hipGraph_t graph = nullptr;
-            uint32_t saved = e->launch_no;                   // capture enqueues nothing: restore the count after it
-            e->g_par0 = (int)(saved & 1u);
             HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
             for (int k = 0; k < graph_chunk; k += unit) {
                 launch_one(e, cards_per_launch, action, reward_out, done_out, obs_out, flags, e->cap_stream);
                 if (prefetch_every && (k + unit) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
             }
             HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
-            e->launch_no = saved;
             hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
             e->g_fused = cards_per_launch; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
             e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
         }
-        if ((int)(e->launch_no & 1u) != e->g_par0)           // a launch with no cards: works the pending lists off, flips parity
-            launch_play(e, true, 0, e->n, nullptr, nullptr, nullptr, nullptr, nullptr, obs_out, flags, s);
         while (left >= graph_chunk) {
             HIPCHK(hipGraphLaunch(e->gexec, s));
-            e->launch_no += (uint32_t)(graph_chunk / unit);
             left -= graph_chunk;
         }
     }
@@ -1532,12 +1563,10 @@ int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void 
     if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out || !obs_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
-    u32 par = e->launch_no & 1u;
-    e->launch_no++;
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     hipLaunchKernelGGL(k_policy_step, grid, dim3(2 * TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset, e->mix, flags,
-                       groups, par, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
+                       groups, e->epoch, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
                        action_out, logp_out, value_out, (ulonglong2 *)feature_words_out, reward_out, done_out, trick_out,
                        (u64 *)obs_out, e->s01, e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount);
     HIPCHK(hipGetLastError());

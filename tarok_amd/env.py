@@ -185,7 +185,8 @@ class TarokVecEnv:
         return Obs(self.obs_words), self.reward, self.done
 
     def prefetch(self):
-        """Deal every slot's next game ahead of time (call at least every 4 auto-reset steps)."""
+        """Fill every next-game line that reset() emptied (reset() calls it itself; afterwards the step
+        launches keep the slots' seven dealt-ahead games full on their own: callers never need this)."""
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_prefetch(self._h, self._stream()))
 

@@ -1,0 +1,170 @@
+"""bench.py's step arithmetic and its JSON line, without a GPU.
+
+Round 1's bench died on the driver's own command (`--steps 20 --warmup 5`: 20 // 48 = 0 launches,
+ZeroDivisionError) — nothing on the CPU side touched that arithmetic.  Here: the pure launch plan
+over every (steps, cards) pair, against a model of what tarok_run_random does with its arguments
+(tarok_env.hip), and the whole of bench.main() on a fake env for the driver's exact flags."""
+import json
+import sys
+import types
+
+import pytest
+import torch
+
+import bench
+
+STEPS = [1, 3, 4, 20, 47, 48, 95, 96, 200, 9600]
+CARDS = [0, 1, 4, 5, 48]
+
+
+def run_random_model(n_steps, cards, graph_chunk):
+    """What tarok_run_random (tarok_env.hip) enqueues: (graph replays, eager launches) or EINVAL."""
+    unit = cards if cards >= 2 else 1
+    if n_steps < 0 or graph_chunk < 0 or graph_chunk > 4096 or not 0 <= cards <= 48:
+        return "EINVAL"
+    if n_steps % unit or graph_chunk % unit:
+        return "EINVAL"
+    left, replays = n_steps, 0
+    if graph_chunk > 0 and left >= graph_chunk:
+        replays = left // graph_chunk
+        left -= replays * graph_chunk
+    return replays, left // unit
+
+
+@pytest.mark.parametrize("cards", CARDS)
+@pytest.mark.parametrize("steps", STEPS)
+def test_plan_never_times_zero_launches_and_matches_the_library(steps, cards):
+    p = bench.plan_region(steps, cards, 1536)
+    unit = max(1, cards)
+    assert p["launches"] == steps >= 1                       # exactly the requested passes are timed
+    assert p["lock_steps"] == steps * unit
+    assert p["launches_per_graph"] >= 1 and p["graph_chunk"] == p["launches_per_graph"] * unit <= p["lock_steps"]
+    assert p["graph_replays"] * p["launches_per_graph"] + p["eager_launches"] == p["launches"]
+    assert run_random_model(p["lock_steps"], cards, p["graph_chunk"]) == (p["graph_replays"], p["eager_launches"])
+    text = bench.describe_mode(p)
+    if cards >= 2:
+        assert "%d card(s)" % cards in text
+    assert ("%d replay(s) of a hipGraph of %d launch(es)" % (p["graph_replays"], p["launches_per_graph"])) in text
+    if p["eager_launches"]:
+        assert "%d eager launch(es)" % p["eager_launches"] in text
+    # a warm-up that captures the timed region's graph: same graph size, at least one whole graph
+    for warm in (0, 1, 5, 960):
+        w = bench.plan_region(warm, cards, 1536, p["launches_per_graph"])
+        assert w["graph_chunk"] == p["graph_chunk"] and w["graph_replays"] >= 1 and w["launches"] >= max(warm, 1)
+        assert run_random_model(w["lock_steps"], cards, w["graph_chunk"]) == (w["graph_replays"], w["eager_launches"])
+
+
+def test_plan_eager_mode():
+    p = bench.plan_region(20, 48, 0)
+    assert p["graph_chunk"] == 0 and p["graph_replays"] == 0 and p["eager_launches"] == 20
+    assert run_random_model(p["lock_steps"], 48, 0) == (0, 20)
+    assert "eager launches" in bench.describe_mode(p)
+
+
+class FakeEnv:
+    """Stands in for TarokVecEnv: records what the bench enqueues."""
+    instances = []
+
+    def __init__(self, n, device=0, seed=0, mix=0, game_offset=0):
+        self.n, self.calls = n, []
+        FakeEnv.instances.append(self)
+
+    def reset(self, episode=0):
+        self.calls.append(("reset",))
+
+    def run_random(self, n_steps, cards_per_launch=None, graph_chunk=0, auto_reset=True):
+        assert run_random_model(n_steps, cards_per_launch, graph_chunk) != "EINVAL"
+        self.calls.append(("run", n_steps, cards_per_launch, graph_chunk))
+
+    def counters(self):
+        import numpy as np
+        return np.zeros(self.n, np.int64), np.zeros((self.n, 4), np.int32)
+
+    def rollout_random(self, episode=0):
+        return {"nsteps": torch.full((self.n,), 40, dtype=torch.int16)}
+
+    def close(self):
+        pass
+
+
+class FakeEvent:
+    def __init__(self, enable_timing=False):
+        pass
+
+    def record(self, stream):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.8
+
+
+@pytest.fixture
+def fake_gpu(monkeypatch):
+    import tarok_amd
+    FakeEnv.instances.clear()
+    monkeypatch.setattr(tarok_amd, "build", lambda *a, **k: None)
+    monkeypatch.setattr(tarok_amd, "TarokVecEnv", FakeEnv, raising=False)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: object())
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    fake_sp = types.ModuleType("tarok_amd.selfplay")
+
+    class SelfPlay:
+        def __init__(self, *a, **k):
+            raise RuntimeError("no GPU in this test")
+    fake_sp.SelfPlay = SelfPlay
+    monkeypatch.setitem(sys.modules, "tarok_amd.selfplay", fake_sp)
+    monkeypatch.setattr(tarok_amd, "selfplay", fake_sp, raising=False)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TAROK_BENCH_ONE_GPU"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("argv", [["--gpus", "1", "--steps", "20", "--warmup", "5"],        # the driver's command
+                                  ["--steps", "1", "--warmup", "0"], ["--steps", "47", "--cards-per-launch", "5"],
+                                  ["--steps", "3", "--cards-per-launch", "1"], []])
+def test_bench_line_on_a_fake_env(fake_gpu, monkeypatch, capsys, argv):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline"] + argv)
+    bench.main()
+    out = capsys.readouterr()
+    line = json.loads(out.out.strip().splitlines()[-1])
+    a = dict(zip(argv[::2], argv[1::2]))
+    steps, cards = int(a.get("--steps", 200)), int(a.get("--cards-per-launch", 48))
+    assert line["steps"] == line["steps_requested"] == steps and line["warmup"] >= line["warmup_requested"]
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["dtype"] == "u64" and line["n_gpus"] == 1
+    assert line["lock_steps_timed"] == steps * cards
+    cfg = line["config"]
+    assert cfg["cards_per_launch"] == cards and cfg["launch_plan"]["launches"] == steps
+    assert "workload" in cfg and "65536" in cfg["workload"]
+    r = line["roofline"]
+    assert r["launch_us"] == pytest.approx(800.0 / steps) and 0 < r["frac"] and r["algorithmic"]["bytes_per_step"] == 54
+    assert r["steps_per_launch"] == 65536 * cards
+    assert line["roofline_step_api"]["frac"] > 0 and line["api_two_kernel"]["value"] > 0
+    # what the env was asked to do in the FIRST timed region is exactly the plan on the line:
+    # reset, warm-up (untimed: holds the graph capture), then `repeats` identical regions
+    env = FakeEnv.instances[0]
+    p = cfg["launch_plan"]
+    runs = [c for c in env.calls if c[0] == "run"]
+    assert runs[0][2] == cards and runs[0][3] == p["graph_chunk"] and runs[0][1] >= p["graph_chunk"]     # warm-up
+    assert runs[1:6] == [("run", p["lock_steps"], cards, p["graph_chunk"])] * 5
+    # the failing self-play leg is visible: error field, side_leg_errors, stderr — and the line is still there
+    assert "error" in line["selfplay_ppo"] and line["side_leg_errors"] and "FAILED" in out.err
+
+
+def test_bench_strict_exits_nonzero_after_printing(fake_gpu, monkeypatch, capsys):
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--strict", "--steps", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 1
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["side_leg_errors"]
+
+
+def test_profile_provenance_is_flagged_stale(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "x.json").write_text(json.dumps({"kernel_src_sha": "abc", "v": 1}))
+    obj, prov = bench.load_profile("x.json", "abc")
+    assert obj["v"] == 1 and prov["stale"] is False
+    obj, prov = bench.load_profile("x.json", "def")
+    assert prov["stale"] is True and prov["measured_on_kernel_src_sha"] == "abc"
+    assert bench.load_profile("missing.json", "abc") == (None, {"source": None})
+    assert len(bench.kernel_src_sha()) == 16
