@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TAROK_ABI_VERSION 2
+#define TAROK_ABI_VERSION 3
 
 #define TAROK_OK 0
 #define TAROK_EINVAL (-1) /* bad argument                                  */
@@ -54,6 +54,11 @@ extern "C" {
 #define TAROK_DEFER_EXCHANGE 1 /* tarok_reset: leave Tri..Solo_ena games waiting for tarok_exchange */
 #define TAROK_AUTO_RESET 2     /* step kernels: re-deal a game in the launch that finishes it        */
 #define TAROK_CLEAR_COUNTERS 4 /* tarok_reset: also zero the per-slot score sums                     */
+#define TAROK_REWARD_REF 8     /* step kernels: reward_out carries what rezultat_igre folds into the last       */
+                               /* transition (Igralec.py:421-437): the scores, except that a Berac / Odprti_berac  */
+                               /* DEFENDER gets -20 when the hands are empty at the end, else +20               */
+#define TAROK_HISTORY 16       /* tarok_create: keep the play history (48 bytes per game), needed by            */
+                               /* tarok_observe_ref                                                              */
 
 /* observation word written by tarok_legal_actions / tarok_step (one u64 per game) */
 #define TAROK_OBS_MASK ((1ULL << 54) - 1) /* [53:0]  legal-card mask of the seat to move  */
@@ -83,7 +88,8 @@ int tarok_last_hip_error(void);    /* last hipError_t seen by this library      
 /* One env = n_games slots on one GPU.  game_offset = global index of slot 0
  * (the deal RNG is keyed by seed, game_offset+g and the slot's episode number,
  * so any sharding over GPUs plays identical games).  Replaces building N Igra
- * objects, Tarok.py:33-35. */
+ * objects, Tarok.py:33-35.  flags: 0, or TAROK_HISTORY (keep the play history:
+ * the `zgodovina` list of Klop.py:63 / Navadna_igra.py:127 as one byte per card). */
 int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_offset,
                  uint64_t seed, int mix, int flags);
 void tarok_destroy(tarok_env *env);
@@ -198,6 +204,62 @@ int tarok_rollout_random(tarok_env *env, uint32_t episode, int16_t *scores_out, 
  *   [192,246) cards already taken, [246] game live. */
 #define TAROK_OBS_FEATURES 256
 int tarok_observe(tarok_env *env, void *features_out, void *stream);
+
+/* ---- the reference's own observation layout (parity unpinned: the reference holds no
+ * fixture for it and Igralec.py cannot be imported — tested against the line-cited restatement
+ * oracle/encoder_spec.py).  Needs an env created with TAROK_HISTORY.
+ *
+ * tarok_observe_ref: what Nevronski_igralec.stanje_v_vektor_rek_navadna (Igralec.py:453-533) builds
+ * for the seat to move of every game in play, as ONE record of 0/1 bytes per game:
+ *   record_out [N, TAROK_REF_RECORD_BYTES] u8, fields at the byte offsets below (row-major):
+ *     TAROK_REF_OPP      [56][3][54]  input_layer_nasprotiki: row i = the i-th card played in the game, one-hot
+ *                                     card in the channel of the opponent who played it (the other three
+ *                                     seats in seat order, Igralec.py:271-274); own plays leave the row empty
+ *     TAROK_REF_OWN      [56][54]     roka_input: row i of an own play = the hand vector before that card; it
+ *                                     starts from the hand as dealt (zacetna_roka; the exchange is not applied)
+ *     TAROK_REF_TALON    [6][55]      talon_input of Tri..Solo_ena (row r: the r-th talon card, column 54: in the
+ *                                     chosen group; all zero for Solo_brez); for Klop the first 54 bytes are its
+ *                                     flat talon vector (the cards gifted so far); zero for Berac
+ *     TAROK_REF_KING     [4]          barva_kralja one-hot (Tri/Dve/Ena)
+ *     TAROK_REF_INDEX    [4]          index_tistega_ki_igra one-hot: the declarer among the other seats in seat
+ *                                     order, 3 = the mover himself
+ *     TAROK_REF_DISCARDS [54]         zalozil (only when the mover is the player who exchanged)
+ *     TAROK_REF_LEGAL    [54]         mozne_vec; 2 bytes of padding follow
+ *   meta_out [N,4] i32 (may be NULL): {T, network type (0 Klop, 1 Navadna_igra, 2 Solo, 3 Berac =
+ *     Nevronski_igralec.Tipi_NN), rows used (cards played so far), seat to move}.  T is the reference's first
+ *     dimension of the two history tensors: the entries of `zgodovina` (cards + the "Talon" entry + Klop's
+ *     talon cards: the counter at Igralec.py:456-458 counts them all) rounded up to the next multiple of 8,
+ *     plus 8 when already one (:460); T <= 56; the reference's tensors are rows [0, T) of the record's.
+ *   Games not in play (finished, waiting for the exchange): an all-zero record and T = 0.
+ *   Which tensors a network type consumes (Igralec.py:520-531): Navadna_igra opp, king, own, talon, index,
+ *   discards, legal; Solo the same without king; Klop opp, own, talon(54), legal; Berac opp, own, index, legal. */
+#define TAROK_REF_ROWS 56
+#define TAROK_REF_OPP 0
+#define TAROK_REF_OWN 9072
+#define TAROK_REF_TALON 12096
+#define TAROK_REF_KING 12426
+#define TAROK_REF_INDEX 12430
+#define TAROK_REF_DISCARDS 12434
+#define TAROK_REF_LEGAL 12488
+#define TAROK_REF_RECORD_BYTES 12544
+int tarok_observe_ref(tarok_env *env, uint8_t *record_out, int32_t *meta_out, void *stream);
+
+/* menjaj_talon_v_vektor (Igralec.py:535-543), the input of the talon-exchange decision, for every game that
+ * waits for tarok_exchange: out [N, TAROK_REF_EXCHANGE_BYTES] u8 = roka [54] (the declarer's hand) | talon
+ * (54,6) flattened card-major (card c lies in group i: byte 54 + 6c + i) | igra one-hot [15]
+ * (igra_zalozi2index, Igralec.py:717-745: (Tri,Dve,Ena) x called suit -> 0..11, Solo_tri/dve/ena -> 12..14)
+ * | 7 bytes of padding.  Zero for games in any other phase. */
+#define TAROK_REF_EXCHANGE_BYTES 400
+int tarok_observe_exchange_ref(tarok_env *env, uint8_t *out, void *stream);
+
+/* The bidding input (pripavi_licitiram, Igralec.py:278-281): out [N,4,54] u8, every seat's hand one-hot. */
+int tarok_observe_hands_ref(tarok_env *env, uint8_t *out, void *stream);
+
+/* The play history of a TAROK_HISTORY env, hist [48,N] u8 (device): card p of every slot's current game
+ * (entries at or beyond the cards played so far are stale).  tarok_set_state does not touch it: a
+ * checkpoint of such an env is the canonical lanes plus this array. */
+int tarok_get_history(tarok_env *env, uint8_t *hist_out, void *stream);
+int tarok_set_history(tarok_env *env, const uint8_t *hist_in, void *stream);
 
 /* A learned player's igraj_karto (cf. Igralec.py:344-355): sample one LEGAL card per game from
  * policy logits.  logits [N,64] bf16 (card c in column c, columns 54..63 ignored), obs [N] the

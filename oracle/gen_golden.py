@@ -478,6 +478,28 @@ class ParalelCtl:
         self.scores.setdefault(gid, {})[p.ime] = int(pts)
 
 
+# the callbacks of the player protocol (Igralec.py:32-122), in the numbering of the recorded call log
+CALLBACKS = ["nova_igra", "pripavi_licitiram", "predict_licitiram", "licitiram", "izberi_barvo_kralja", "konec_licitiranja",
+             "pripravi_izbral_iz_talona", "predict_izberi_iz_talona", "menjaj_iz_talona", "izbral_iz_talona",
+             "poglej_karte_odprtega_beraca", "pripravi_igraj_karto", "predict_igraj_karto", "igraj_karto", "rezultat_stiha",
+             "rezultat_igre"]
+# position of the game id among each callback's positional arguments (-1: a batch barrier, no game)
+ID_ARG = [2, 0, -1, 1, 0, 2, 2, -1, 2, 2, 1, 3, -1, 3, 2, 2]
+
+
+def logged(cls, log):
+    """Subclass of a duck-typed player that appends (callback number, game id or -1, player name) to `log`
+    before every protocol callback: the ORDER in which the reference's scheduler and engines call up."""
+    def wrap(name, k):
+        def f(self, *a, **kw):
+            gid = -1 if ID_ARG[k] < 0 else int(kw["id_igre"] if "id_igre" in kw else a[ID_ARG[k]])
+            log.append((k, gid, int(self.ime)))
+            return getattr(cls, name)(self, *a, **kw)
+        f.__name__ = name
+        return f
+    return type("Logged" + cls.__name__, (cls,), {name: wrap(name, k) for k, name in enumerate(CALLBACKS)})
+
+
 def gen_paralel(seed, n_games, mix):
     R = REF
     perms = [S.deal(S.game_key(seed, g, 0)) for g in range(n_games)]
@@ -487,7 +509,8 @@ def gen_paralel(seed, n_games, mix):
         lst[:] = next(it)           # Igra objects deal in id order (Tarok.py:36-38)
     R["Igra"].shuffle = fake_shuffle
     ctl = ParalelCtl(seed, mix, perms)
-    players = [TracePlayer(i, ctl) for i in range(4)]
+    calls = []
+    players = [logged(TracePlayer, calls)(i, ctl) for i in range(4)]
     t = R["Tarok"].Tarok(players, n_games)
     import contextlib
     import io
@@ -500,7 +523,8 @@ def gen_paralel(seed, n_games, mix):
             per_game[g, i] = ctl.scores[g][str(i)]
     setup = np.array([ctl.setup[g] for g in range(n_games)], np.int8)
     return dict(seed=np.int64(seed), mix=np.int32(mix), deals=np.array(perms, np.uint8),
-                setup=setup, per_game_scores=per_game, totals=np.array(totals, np.int64))
+                setup=setup, per_game_scores=per_game, totals=np.array(totals, np.int64),
+                calls=np.array(calls, np.int16), call_names=np.array(CALLBACKS))
 
 
 # --------------------------------------------------------------------------
@@ -571,9 +595,15 @@ def main():
     ap.add_argument("--procs", type=int, default=max(1, (os.cpu_count() or 2) - 1))
     ap.add_argument("--skip-large", action="store_true")
     ap.add_argument("--only-bidding", action="store_true")
+    ap.add_argument("--only-paralel", action="store_true", help="regenerate paralel_v1.npz alone")
     args = ap.parse_args()
     load_reference(args.reference)
     os.makedirs(args.out, exist_ok=True)
+    if args.only_paralel:
+        par = gen_paralel(seed=5, n_games=96, mix=S.MIX_ALL)
+        np.savez_compressed(os.path.join(args.out, "paralel_v1.npz"), **par)
+        print("paralel totals:", par["totals"], "calls:", len(par["calls"]))
+        return
 
     bid = gen_bidding(1500, seed=77)
     with open(os.path.join(args.out, "licitacija_v1.json"), "w") as f:

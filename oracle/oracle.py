@@ -88,6 +88,30 @@ class Game:
         lib().to_synth_game(C.byref(self.g), seed, gidx, episode, mix)
         return self
 
+    @classmethod
+    def from_lanes(cls, lanes):
+        """A game rebuilt from the canonical lanes (include/tarok_env.h TAROK_LANE_*): the inverse of lanes()."""
+        self = cls()
+        g = self.g
+        for s in range(4):
+            g.hand[s], g.pile[s] = int(lanes[s]), int(lanes[4 + s])
+        tal, m = int(lanes[8]), int(lanes[9])
+        for i in range(6):
+            g.talon[i] = (tal >> (6 * i)) & 63
+        g.n_in_trick = (m >> 24) & 7
+        for i in range(4):
+            g.trick[i] = (m >> (6 * i)) & 63 if i < g.n_in_trick else 0
+        g.leader, g.trick_no, g.contract, g.declarer = (m >> 27) & 3, (m >> 29) & 15, (m >> 33) & 15, (m >> 37) & 3
+        king, choice = (m >> 39) & 7, (m >> 49) & 7
+        g.king = -1 if king == 7 else king
+        g.team, g.talon_left = (m >> 42) & 15, (m >> 46) & 7
+        g.choice = -1 if choice == 7 else choice
+        g.phase, g.error = (m >> 52) & 3, (m >> 54) & 1
+        return self
+
+    def obs_word(self, finished_now=False):
+        return int(lib().to_obs_word(C.byref(self.g), 1 if finished_now else 0))
+
     def exchange(self, choice, discards):
         d = list(discards) + [255] * (3 - len(discards))
         return lib().to_exchange(C.byref(self.g), int(choice), u8arr(d))

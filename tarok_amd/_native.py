@@ -19,6 +19,7 @@ SYMBOLS = [
     "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_reset", "tarok_exchange",
     "tarok_legal_actions", "tarok_step", "tarok_prefetch", "tarok_policy_random", "tarok_step_random",
     "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy", "tarok_policy_mlp", "tarok_policy_step", "tarok_expand_features", "tarok_ppo_loss",
+    "tarok_observe_ref", "tarok_observe_exchange_ref", "tarok_observe_hands_ref", "tarok_get_history", "tarok_set_history",
 ]
 
 
@@ -126,6 +127,11 @@ def lib():
     L.tarok_expand_features.restype = i32; L.tarok_expand_features.argtypes = [vp, i64, vp, vp, vp, vp]
     f32 = C.c_float
     L.tarok_ppo_loss.restype = i32; L.tarok_ppo_loss.argtypes = [vp, i64] + [vp] * 7 + [f32] * 3 + [vp] * 4
+    L.tarok_observe_ref.restype = i32; L.tarok_observe_ref.argtypes = [vp, vp, vp, vp]
+    L.tarok_observe_exchange_ref.restype = i32; L.tarok_observe_exchange_ref.argtypes = [vp, vp, vp]
+    L.tarok_observe_hands_ref.restype = i32; L.tarok_observe_hands_ref.argtypes = [vp, vp, vp]
+    L.tarok_get_history.restype = i32; L.tarok_get_history.argtypes = [vp, vp, vp]
+    L.tarok_set_history.restype = i32; L.tarok_set_history.argtypes = [vp, vp, vp]
     L.tarok_debug_stamps.restype = i32; L.tarok_debug_stamps.argtypes = [vp, vp]
     L.tarok_set_state.restype = i32; L.tarok_set_state.argtypes = [vp, vp, vp]
     L.tarok_get_counters.restype = i32; L.tarok_get_counters.argtypes = [vp, vp, vp, vp]

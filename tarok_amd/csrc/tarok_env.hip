@@ -29,9 +29,11 @@
 
 #include "../../include/tarok_env.h"
 
-#define TK_BLOCK 256
-#define TK_PF_SLOTS 1024
-#define TK_REFILL_CAP (256 * TK_AHEAD) // refill-list entries per play workgroup and launch (<= TK_AHEAD per slot)
+#ifndef TK_BLOCK
+#define TK_BLOCK 256               // (512 / 1024: diagnostics builds only, tools/ab_build.sh — more play waves per SIMD on fewer CUs)
+#endif
+#define TK_PF_SLOTS (4 * TK_BLOCK)
+#define TK_REFILL_CAP (TK_BLOCK * TK_AHEAD) // refill-list entries per play workgroup and launch (<= TK_AHEAD per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 // list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
 // different XCDs, whose L2s are not coherent: two of them must never write into one line
@@ -60,7 +62,7 @@ struct __attribute__((aligned(64))) AuxLine {
 };
 struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
 static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 64 * TK_AHEAD, "64 bytes per next-game line");
-static_assert((256 * sizeof(Aux)) % 128 == 0, "a play group's next-game lines end on an L2 line boundary");
+static_assert((TK_BLOCK * sizeof(Aux)) % 128 == 0, "a play group's next-game lines end on an L2 line boundary");
 static_assert(TK_AHEAD >= 2 && TK_AHEAD <= 7, "epar / cprev are 3-bit fields");
 // What a finishing game always touches: the slot's episode number and its summed scores.  Kept
 // apart from the next-game lines: those are written by refill workgroups, these by the slot's own
@@ -84,6 +86,7 @@ struct tarok_env {
     uint8_t *nstale;         // bit k: the game k+1 ahead is missing and not on any refill list
                              // (after tarok_reset; what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
+    uint8_t *hist;           // [48][n] play history (card p of the slot's current game), TAROK_HISTORY envs only
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
     u32 *rcount;             // [play workgroups][2]
     u32 *epoch;              // [0] launch epoch (its low bit = parity of the refill list a launch writes; it works the
@@ -339,12 +342,12 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
 // plays slot group * 256 + tid; threads with active = false (a larger workgroup's extra threads)
 // only take part in the two barriers.  The card comes from action_in, or (action_in == NULL) from
 // a_reg, or with RANDOM from the in-kernel Bot policy.
-template <bool RANDOM>
+template <bool RANDOM, bool HIST>
 __device__ __forceinline__ void play_role(
     u32 group, u32 tid, bool active, u32 a_reg,
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 par,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
-    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
+    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
     __shared__ u64 push_list[TK_REFILL_CAP];
@@ -423,8 +426,14 @@ __device__ __forceinline__ void play_role(
         u64 scores = 0;
         u32 trick_info = 0;
         int res = -2;
+        const u32 pos = g.trick_no * 4 + g.nt;            // cards played so far in this game
+        const u32 d_fin = g.declarer;
+        const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
         if (play) res = RANDOM ? apply_step<true>(g, a, scores, trick_info) : apply_step<false>(g, a, scores, trick_info);
         bool fin = res == 1;
+        // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
+        // write-only here; only the reference-layout observation (k_observe_ref) reads it
+        if (HIST && hist && play && res >= 0) hist[(int64_t)pos * n + i] = (uint8_t)a;
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
         if (v) {
@@ -434,7 +443,17 @@ __device__ __forceinline__ void play_role(
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
         if (CAN_END && fin) {
-            if (reward) reinterpret_cast<u64 *>(reward)[row] = scores;
+            if (reward) {
+                u64 rs = scores;
+                if ((flags & TAROK_REWARD_REF) && berac_fin) {
+                    // what rezultat_igre folds into a Berac defender's last transition (Igralec.py:434-437):
+                    // -20 when the hands are empty at the end (all twelve tricks were played), else +20
+                    int dv = g.trick_no >= 12 ? -20 : 20;
+                    rs = pack_scores(d_fin == 0 ? (int)(int16_t)(scores & 0xFFFF) : dv, d_fin == 1 ? (int)(int16_t)((scores >> 16) & 0xFFFF) : dv,
+                                     d_fin == 2 ? (int)(int16_t)((scores >> 32) & 0xFFFF) : dv, d_fin == 3 ? (int)(int16_t)(scores >> 48) : dv);
+                }
+                reinterpret_cast<u64 *>(reward)[row] = rs;
+            }
             acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
             acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
             acc_dirty = true;
@@ -557,19 +576,20 @@ __device__ __forceinline__ void play_role(
 
 // (at most 128 VGPRs: four waves per SIMD for the throughput-bound batch sizes; the specialised
 // card loops would otherwise take 131)
-template <bool RANDOM>
+// HIST: also record the play history (one byte per card; tarok_create flag TAROK_HISTORY)
+template <bool RANDOM, bool HIST>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
-    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs,
+    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
     u32 ep = launch_epoch(epoch), par = ep & 1u;
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
     else
-        play_role<RANDOM>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in, action_out,
-                          reward, done, trick, obs, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
+        play_role<RANDOM, HIST>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in,
+                                action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
     launch_done(epoch, ep);
 }
 
@@ -667,6 +687,269 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe(int64_t n, const ulonglong
         v.y = ((nib & 4) ? 0x3F80u : 0u) | ((nib & 8) ? 0x3F800000u : 0u);
         out[(wave_base + l) * 64 + lane] = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// The reference's OWN observation layout: what Nevronski_igralec builds for the
+// seat to move in stanje_v_vektor_rek_navadna (Igralec.py:453-533), as one dense record of 0/1
+// bytes per game (offsets TAROK_REF_* in tarok_env.h; a consumer slices views out of it):
+//   opponents' history [56][3][54]  row i = the i-th card PLAYED in the game (talon entries of the
+//                                   history do not take a row): one-hot card in the channel of the
+//                                   opponent who played it, channels = the other seats in seat order
+//                                   (igralci2index, Igralec.py:271-274)                      :508-510
+//   own-hand history   [56][54]     row i of an own play = the hand vector before that card, which
+//                                   starts from the hand as DEALT (zacetna_roka: the exchange is not
+//                                   applied to it, discards stay set)                        :465,511-514
+//   talon              [6][55]      Tri..Solo_ena: row r = one-hot of the r-th talon card, column 54 =
+//                                   "in the chosen group" (:499-507); Klop: a flat 54-vector of the
+//                                   talon cards gifted so far (:497-498); Berac: nothing (:487-488)
+//   king one-hot [4] (:467-470), declarer-relative index one-hot [4] (:493-494, self = 3),
+//   discards [54] (only in the view of the player who exchanged, :462-464), legal cards [54] (:518-519)
+// plus meta = {T, network type, rows used, seat}: T = entries of the history — played cards + the
+// "Talon" entry + Klop's talon gifts: the counter at :456-458 counts every entry — rounded up to the
+// next multiple of 8, plus 8 when already one (:460); the reference's tensors have T rows, the
+// record always 56 (rows >= rows-used are zero either way).
+// Parity unpinned: the reference holds no fixture for this layout and Igralec.py cannot be imported
+// (pytorch_lightning, torch_models); tested against a line-cited restatement (oracle/encoder_spec.py).
+//
+// Phase 1, one thread per game: history bytes -> LDS, trick leaders replayed from the cards (the
+// winner rule of apply_step), initial hand and discards recovered from the planes, the 448 bits of
+// the small fields.  Phase 2, one wave per game at a time: lane t builds row t (an exclusive
+// prefix-OR over the lanes gives "own cards played before"), then the 64 lanes write the 12,544-byte
+// record as 784 16-byte chunks, each computed from the row descriptors: full-line stores.
+#define OR_ROWS 56
+#define OR_OWN_OFF (OR_ROWS * 162)
+#define OR_SMALL_OFF (OR_OWN_OFF + OR_ROWS * 54)
+#define OR_REC (OR_SMALL_OFF + 448)
+static_assert(OR_REC == TAROK_REF_RECORD_BYTES && OR_OWN_OFF == TAROK_REF_OWN && OR_SMALL_OFF == TAROK_REF_TALON, "record layout");
+
+struct RefDesc { u64 h0; u64 small[7]; u32 leaders, plays, me, pad; };
+
+// 4 bits -> 4 bytes of 0/1 (the four shifted copies do not overlap: no carries)
+__device__ __forceinline__ u32 nibble_bytes(u32 x) { return ((x & 15u) * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ uint4 bits16_bytes(u32 b) {
+    return make_uint4(nibble_bytes(b), nibble_bytes(b >> 4), nibble_bytes(b >> 8), nibble_bytes(b >> 12));
+}
+// OR `val` (WIDTH <= 64 bits) into a little-endian bit vector at the compile-time bit offset OFF
+template <int OFF, int NW> __device__ __forceinline__ void bits_insert(u64 (&w)[NW], u64 val) {
+    w[OFF / 64] |= val << (OFF % 64);
+    if (OFF % 64 != 0 && OFF / 64 + 1 < NW) w[OFF / 64 + 1] |= val >> (64 - OFF % 64);
+}
+// set bit `b` (run-time index) of a bit vector kept in registers
+template <int NW> __device__ __forceinline__ void bits_set(u64 (&w)[NW], u32 b) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] |= ((b >> 6) == (u32)k) ? (1ULL << (b & 63)) : 0ULL;
+}
+__device__ __forceinline__ u32 ref_type(u32 c) {    // Nevronski_igralec.tip_igre_v_tip_izbire (Igralec.py:180-189), Tipi_NN values
+    return c == TK_KLOP ? 0u : (has_king(c) ? 1u : ((c == TK_BERAC || c == TK_ODPRTI_BERAC) ? 3u : 2u));
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_observe_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                         const ulonglong2 *__restrict__ s23, const uint8_t *__restrict__ hist,
+                                                         uint4 *__restrict__ rec, int4 *__restrict__ meta) {
+    __shared__ RefDesc desc[TK_BLOCK];
+    __shared__ uint8_t hist_s[TK_BLOCK][48];
+    __shared__ uint8_t rowpos_s[TK_BLOCK / 64][64];
+    __shared__ u64 rowmask_s[TK_BLOCK / 64][64];
+    u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t base = (int64_t)blockIdx.x * TK_BLOCK;
+    {   // ---- phase 1
+        int64_t i = base + tid;
+        bool valid = i < n;
+        int64_t ic = valid ? i : n - 1;
+        Game g;
+        load_game(g, s01, s23, ic);
+        bool live = valid && g.phase == TK_PHASE_PLAY;
+        u32 me = (g.leader + g.nt) & 3;
+        u32 plays = live ? g.trick_no * 4 + g.nt : 0u;
+        bool berac = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
+        u32 lead = berac ? g.declarer : 0u;                               // Berac.py:15, Klop.py:26, Navadna_igra.py:70
+        u32 leaders = 0;
+        u64 played_all = 0, played_me = 0;
+        for (u32 t = 0; t < 12; t++) {
+            if (t * 4 >= plays) break;
+            leaders |= lead << (2 * t);
+            u32 c[4];
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) {
+                u32 idx = t * 4 + j;
+                bool has = idx < plays;
+                c[j] = has ? (u32)hist[(int64_t)idx * n + ic] & 63u : 0u;
+                hist_s[tid][idx] = (uint8_t)c[j];
+                u64 bit = has ? (1ULL << c[j]) : 0ULL;
+                played_all |= bit;
+                played_me |= (((lead + j) & 3) == me) ? bit : 0ULL;
+            }
+            if (t * 4 + 4 <= plays) {                                     // pobere_stih (Klop.py:81-94)
+                u32 w = 0, cw = c[0];
+#pragma unroll
+                for (u32 j = 1; j < 4; j++) {
+                    u32 sw = min(cw >> 3, 4u), si = min(c[j] >> 3, 4u);
+                    bool beats = (sw == si) ? (cw < c[j]) : (si == 4);
+                    w = beats ? j : w;
+                    cw = beats ? c[j] : cw;
+                }
+                lead = (lead + w) & 3;
+            }
+        }
+        // zacetna_roka (Igralec.py:264): the hand as dealt.  hand now + own cards played = the hand after
+        // the exchange = (dealt + chosen group) - discards; the discards are what lies in the exchanging
+        // player's pile without ever having been played (Igralec.py:376-377)
+        u64 h_after = hand_of(g, me) | played_me;
+        u64 h0 = h_after, disc = 0;
+        bool exch = has_exchange(g.contract);
+        u32 gs = exch ? group_size(g.contract) : 1u;
+        if (exch && me == g.declarer) {
+            u64 grp = ids_mask(g.talon, (int)(g.tl * gs), (int)gs);
+            disc = seat_cards(g, g.declarer) & g.C & ~played_all;
+            h0 = (h_after & ~grp) | (disc & ~grp);
+        }
+        u64 small[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (live) {
+            if (exch) {                                                   // the ("Talon", ...) entry, :499-507
+#pragma unroll
+                for (u32 r = 0; r < 6; r++) {
+                    bits_set(small, r * 55 + (u32)((g.talon >> (6 * r)) & 63));
+                    if (r / gs == g.tl) bits_set(small, r * 55 + 54);
+                }
+            } else if (g.contract == TK_KLOP) {                           // (None, talon card) entries, :497-498
+#pragma unroll
+                for (u32 r = 0; r < 6; r++)
+                    if (r >= g.tl) bits_set(small, (u32)((g.talon >> (6 * r)) & 63));
+            }
+            if (has_king(g.contract)) bits_insert<330>(small, 1ULL << g.king);                       // :467-470
+            u32 didx = g.declarer == me ? 3u : (g.declarer < me ? g.declarer : g.declarer - 1);     // :271-274, 449-451
+            if (g.contract != TK_KLOP) bits_insert<334>(small, 1ULL << didx);                         // (Klop's list has no index, :526-527)
+            bits_insert<338>(small, disc);
+            bits_insert<392>(small, legal_now(g));
+        }
+        RefDesc &d = desc[tid];
+        d.h0 = live ? h0 : 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) d.small[k] = small[k];
+        d.leaders = leaders; d.plays = plays; d.me = me;
+        if (valid && meta) {
+            u32 entries = plays + (exch ? 1u : 0u) + (g.contract == TK_KLOP ? 6u - g.tl : 0u);       // :455-458
+            u32 T = entries + (8 - entries % 8);                                                      // :460
+            meta[i] = make_int4(live ? (int)T : 0, (int)ref_type(g.contract), (int)plays, (int)me);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: this wave's 64 games, one at a time
+    for (u32 k = 0; k < 64; k++) {
+        u32 gl = wave * 64 + k;
+        int64_t gidx = base + gl;
+        if (gidx >= n) break;                                             // wave uniform
+        const RefDesc &d = desc[gl];
+        u32 me = d.me, plays = d.plays;
+        u32 pos = 255;
+        u64 mybit = 0;
+        if (lane < plays) {
+            u32 c = hist_s[gl][lane];
+            u32 seat = (((d.leaders >> (2 * (lane >> 2))) & 3) + (lane & 3)) & 3;
+            if (seat == me) mybit = 1ULL << c;
+            else pos = (seat < me ? seat : seat - 1) * 54 + c;
+        }
+        u32 lo = (u32)mybit, hi = (u32)(mybit >> 32);                     // inclusive prefix OR over the rows
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 l2 = (u32)__shfl_up((int)lo, o), h2 = (u32)__shfl_up((int)hi, o);
+            if ((int)lane >= o) { lo |= l2; hi |= h2; }
+        }
+        u64 before = TK_U64(lo, hi) & ~mybit;                             // own cards played before this row
+        rowpos_s[wave][lane] = (uint8_t)pos;
+        rowmask_s[wave][lane] = mybit ? (d.h0 & ~before) : 0ULL;          // :512 (the hand before the card leaves it)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0): the wave's LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        for (u32 ch = lane; ch < OR_REC / 16; ch += 64) {
+            u32 o = ch * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o < OR_OWN_OFF) {
+                u32 t0 = o / 162;
+#pragma unroll
+                for (u32 q = 0; q < 2; q++) {
+                    u32 t = t0 + q;
+                    u32 pp = rowpos_s[wave][t & 63];
+                    u32 idx = t * 162 + pp - o;
+                    if (t < 64 && pp < 162 && idx < 16) {
+                        u32 b = 1u << ((idx & 3) * 8);
+                        v.x |= (idx >> 2) == 0 ? b : 0; v.y |= (idx >> 2) == 1 ? b : 0;
+                        v.z |= (idx >> 2) == 2 ? b : 0; v.w |= (idx >> 2) == 3 ? b : 0;
+                    }
+                }
+            } else if (o < OR_SMALL_OFF) {
+                u32 rel = o - OR_OWN_OFF, t0 = rel / 54, b0 = rel - t0 * 54;
+                u64 m = (rowmask_s[wave][t0] >> b0) | (rowmask_s[wave][(t0 + 1) & 63] << (54 - b0));
+                v = bits16_bytes((u32)m & 0xFFFFu);
+            } else {
+                u32 rel = o - OR_SMALL_OFF;
+                v = bits16_bytes((u32)(d.small[rel >> 6] >> (rel & 63)) & 0xFFFFu);
+            }
+            rec[gidx * (OR_REC / 16) + ch] = v;
+        }
+        __builtin_amdgcn_wave_barrier();                                  // the row buffers are rewritten by the next game
+    }
+}
+
+// A block's per-game bit vectors (NW words each, in LDS) written as 0/1 bytes, BYTES per game (a multiple
+// of 8), wave-cooperatively: a game's record leaves as consecutive 8-byte stores of neighbouring lanes.
+template <int NW, int BYTES>
+__device__ __forceinline__ void write_bit_records(const u64 (*words)[NW], int64_t base, int64_t n, uint2 *__restrict__ out) {
+    static_assert(BYTES % 8 == 0 && BYTES <= NW * 64, "record size");
+    u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 k = 0; k < 64; k++) {
+        u32 gl = wave * 64 + k;
+        int64_t gidx = base + gl;
+        if (gidx >= n) break;
+        for (u32 ch = lane; ch < BYTES / 8; ch += 64) {
+            u32 b = (u32)(words[gl][ch >> 3] >> ((ch & 7) * 8)) & 255u;
+            out[gidx * (BYTES / 8) + ch] = make_uint2(nibble_bytes(b), nibble_bytes(b >> 4));
+        }
+    }
+}
+
+// menjaj_talon_v_vektor (Igralec.py:535-543), the input of the exchange decision, for the games that
+// wait for tarok_exchange: [roka 54 | talon (54,6) flattened card-major | igra one-hot 15 | pad 7]
+// = 400 bytes of 0/1; zeros for games in any other phase.
+__global__ __launch_bounds__(TK_BLOCK) void k_observe_exchange_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                                  const ulonglong2 *__restrict__ s23, uint2 *__restrict__ out) {
+    __shared__ u64 words[TK_BLOCK][7];
+    int64_t base = (int64_t)blockIdx.x * TK_BLOCK, i = base + threadIdx.x;
+    Game g;
+    load_game(g, s01, s23, i < n ? i : n - 1);
+    u64 w[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (i < n && g.phase == TK_PHASE_EXCHANGE) {
+        u32 gs = group_size(g.contract);
+        bits_insert<0>(w, hand_of(g, g.declarer));                        // :540 (the hand before the exchange)
+#pragma unroll
+        for (u32 r = 0; r < 6; r++) bits_set(w, 54 + (u32)((g.talon >> (6 * r)) & 63) * 6 + r / gs);   // :541-542
+        // igra_zalozi2index (Igralec.py:717-745): Tri/Dve/Ena x suit -> 0..11, Solo_tri/dve/ena -> 12..14
+        u32 idx = has_king(g.contract) ? (g.contract - 1) * 4 + g.king : 12 + (g.contract - TK_SOLO_TRI);
+        bits_set(w, 378 + idx);                                           // :539
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) words[threadIdx.x][k] = w[k];
+    __syncthreads();
+    write_bit_records<7, TAROK_REF_EXCHANGE_BYTES>(words, base, n, out);
+}
+
+// The bidding input (pripavi_licitiram, Igralec.py:278-281): every seat's hand as 54 bytes of 0/1,
+// [N][4][54].
+__global__ __launch_bounds__(TK_BLOCK) void k_observe_hands_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                               const ulonglong2 *__restrict__ s23, uint2 *__restrict__ out) {
+    __shared__ u64 words[TK_BLOCK][4];
+    int64_t base = (int64_t)blockIdx.x * TK_BLOCK, i = base + threadIdx.x;
+    Game g;
+    load_game(g, s01, s23, i < n ? i : n - 1);
+    u64 w[4] = {0, 0, 0, 0};
+    if (i < n) {
+        bits_insert<0>(w, hand_of(g, 0)); bits_insert<54>(w, hand_of(g, 1));
+        bits_insert<108>(w, hand_of(g, 2)); bits_insert<162>(w, hand_of(g, 3));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) words[threadIdx.x][k] = w[k];
+    __syncthreads();
+    write_bit_records<4, 216>(words, base, n, out);
 }
 
 // Masked categorical sample from policy logits, one thread per game: softmax over the legal
@@ -880,6 +1163,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_ppo_loss(int64_t n, const uint4 *_
 // stores).  Layers 1-2: wave w owns features [64w, 64w+64) x all 128 games (2 x 4 tiles, 128 MFMAs,
 // the weight slab streamed from L2 four k-steps ahead); layer 3 (64 outputs = 54 card logits, value
 // in column 54): wave w owns games [32w, 32w+32).
+#if TK_BLOCK == 256                // the MLP kernels are laid out for 256-slot groups
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -1173,7 +1457,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
     ulonglong2 *__restrict__ feature_words_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
-    uint16_t *__restrict__ trick, u64 *__restrict__ obs_out,
+    uint16_t *__restrict__ trick, u64 *__restrict__ obs_out, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
     u32 ep = launch_epoch(epoch), par = ep & 1u;
@@ -1187,10 +1471,12 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
                    act_s);
     __syncthreads();
     u32 tid = threadIdx.x;
-    play_role<false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n, par,
-                     nullptr, nullptr, reward, done, trick, obs_out, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
+    play_role<false, true>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n,
+                           par, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
     launch_done(epoch, ep);
 }
+
+#endif  // TK_BLOCK == 256
 
 __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
                                                       int4 *__restrict__ score_sum) {
@@ -1300,7 +1586,7 @@ int tarok_device_count(void) {
 }
 
 int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_offset, uint64_t seed, int mix, int flags) {
-    if (!out || n_games <= 0 || n_games > (1LL << 31)) return TAROK_EINVAL;
+    if (!out || n_games <= 0 || n_games > (1LL << 31) || (flags & ~TAROK_HISTORY)) return TAROK_EINVAL;
     if (!(mix == TAROK_MIX_ALL || mix == TAROK_MIX_NAVADNA3 || mix == TAROK_MIX_BOT || (mix >= TAROK_MIX_FIXED && mix < TAROK_MIX_FIXED + 10))) return TAROK_EINVAL;
     if (device < 0 || device >= tarok_device_count()) return TAROK_ENODEV;
     HIPCHK(hipSetDevice(device));
@@ -1317,6 +1603,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     if (r == hipSuccess) r = hipMalloc((void **)&e->cnt, (size_t)n_games * sizeof(Counters));
     if (r == hipSuccess) r = hipMalloc((void **)&e->nstale, stale_bytes);
     if (r == hipSuccess) r = hipMalloc((void **)&e->gkey, (size_t)n_games * sizeof(u64));
+    if (r == hipSuccess && (flags & TAROK_HISTORY)) r = hipMalloc((void **)&e->hist, (size_t)n_games * 48);
+    if (r == hipSuccess && e->hist) r = hipMemset(e->hist, 255, (size_t)n_games * 48);
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
@@ -1345,7 +1633,7 @@ void tarok_destroy(tarok_env *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
-    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch);
+    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch); (void)hipFree(e->hist);
     delete e;
 }
 
@@ -1404,14 +1692,15 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
-    if (random)
-        hipLaunchKernelGGL(k_play<true>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
-                           e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
-    else
-        hipLaunchKernelGGL(k_play<false>, grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride,
-                           groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->s01, e->s23, e->aux,
-                           e->cnt, e->gkey, e->rlist, e->rcount, e->stamps);
+    // (the external-policy kernel always carries the history code: one uniform test of `hist` per launch)
+#define TK_LAUNCH_PLAY(R, H)                                                                                                \
+    hipLaunchKernelGGL((k_play<R, H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
+                       groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01,     \
+                       e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, e->stamps)
+    if (!random) TK_LAUNCH_PLAY(false, true);
+    else if (e->hist) TK_LAUNCH_PLAY(true, true);
+    else TK_LAUNCH_PLAY(true, false);
+#undef TK_LAUNCH_PLAY
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
@@ -1533,6 +1822,48 @@ int tarok_observe(tarok_env *e, void *features_out, void *stream) {
     return TAROK_OK;
 }
 
+int tarok_observe_ref(tarok_env *e, uint8_t *record_out, int32_t *meta_out, void *stream) {
+    if (!e || !record_out) return TAROK_EINVAL;
+    if (!e->hist) return TAROK_EINVAL;                                   // needs a TAROK_HISTORY env
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_observe_ref, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, e->hist,
+                       (uint4 *)record_out, (int4 *)meta_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_observe_exchange_ref(tarok_env *e, uint8_t *out, void *stream) {
+    if (!e || !out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_observe_exchange_ref, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23,
+                       (uint2 *)out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_observe_hands_ref(tarok_env *e, uint8_t *out, void *stream) {
+    if (!e || !out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_observe_hands_ref, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23,
+                       (uint2 *)out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_get_history(tarok_env *e, uint8_t *hist_out, void *stream) {
+    if (!e || !hist_out || !e->hist) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(hist_out, e->hist, (size_t)e->n * 48, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TAROK_OK;
+}
+
+int tarok_set_history(tarok_env *e, const uint8_t *hist_in, void *stream) {
+    if (!e || !hist_in || !e->hist) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->hist, hist_in, (size_t)e->n * 48, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TAROK_OK;
+}
+
 int tarok_sample_policy(tarok_env *e, const void *logits_bf16, const uint64_t *obs, uint8_t *action_out,
                         float *logp_out, void *stream) {
     if (!e || !logits_bf16 || !obs || !action_out) return TAROK_EINVAL;
@@ -1547,6 +1878,9 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
                      const float *b3, const uint64_t *obs, uint8_t *action_out, float *logp_out, float *value_out,
                      void *features_out, uint64_t *feature_words_out, void *stream) {
     if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out) return TAROK_EINVAL;
+#if TK_BLOCK != 256
+    return TAROK_EINVAL;
+#else
     HIPCHK(hipSetDevice(e->device));
     dim3 grid((unsigned)((e->n + PM_M - 1) / PM_M));
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
@@ -1554,6 +1888,7 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
                        value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, e->stamps);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
+#endif
 }
 
 int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void *w2, const float *b2, const void *w3,
@@ -1561,6 +1896,9 @@ int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void 
                       uint64_t *feature_words_out, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,
                       uint64_t *obs_out, int flags, void *stream) {
     if (!e || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !obs || !action_out || !obs_out) return TAROK_EINVAL;
+#if TK_BLOCK != 256
+    return TAROK_EINVAL;
+#else
     HIPCHK(hipSetDevice(e->device));
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 fan = e->refill_fan;
@@ -1568,9 +1906,10 @@ int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void 
     hipLaunchKernelGGL(k_policy_step, grid, dim3(2 * TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset, e->mix, flags,
                        groups, e->epoch, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
                        action_out, logp_out, value_out, (ulonglong2 *)feature_words_out, reward_out, done_out, trick_out,
-                       (u64 *)obs_out, e->s01, e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount);
+                       (u64 *)obs_out, e->hist, e->s01, e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
+#endif
 }
 
 int tarok_expand_features(tarok_env *e, int64_t n_samples, const uint64_t *feature_words, const int64_t *index,

@@ -54,7 +54,7 @@ class Obs:
 
 
 class TarokVecEnv:
-    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0):
+    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False):
         self._h = None
         L = _native.lib()
         if not torch.cuda.is_available() or L.tarok_device_count() == 0:
@@ -65,7 +65,9 @@ class TarokVecEnv:
         self.device = torch.device("cuda", self.device_index)
         self.seed, self.mix, self.game_offset = int(seed), int(mix), int(game_offset)
         h = C.c_void_p()
-        _native.check(L.tarok_create(C.byref(h), self.device_index, self.n, self.game_offset, self.seed, self.mix, 0))
+        self.history = bool(history)
+        _native.check(L.tarok_create(C.byref(h), self.device_index, self.n, self.game_offset, self.seed, self.mix,
+                                     K.HISTORY if history else 0))
         self._h = h
         with torch.cuda.device(self.device):
             self.obs_words = torch.zeros(self.n, dtype=torch.int64, device=self.device)
@@ -142,8 +144,10 @@ class TarokVecEnv:
                 self.trick = torch.zeros(self.n, dtype=torch.int16, device=self.device)
         return self.trick if tricks else None
 
-    def step(self, action, auto_reset=False, tricks=False, obs_out=None, reward_out=None, done_out=None):
+    def step(self, action, auto_reset=False, tricks=False, obs_out=None, reward_out=None, done_out=None, reward_ref=False):
         """One card per game.  Returns (Obs, reward[N,4] i16 — valid where done, done[N] u8).
+        reward_ref=True: reward carries what rezultat_igre folds into the last transition (Igralec.py:421-437:
+        the scores, but -20 / +20 for the defenders of a Berac) instead of the plain scores.
         tricks=True also fills self.trick [N] i16: 0, or 0x8000 | vrednost_stiha<<4 | winner seat
         for games whose trick this card completed (what rezultat_stiha is told).
         obs_out / reward_out / done_out: caller-owned device tensors to write into instead of
@@ -155,7 +159,8 @@ class TarokVecEnv:
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_step(self._h, self._p(a), self._p(rw), self._p(dn),
                                             self._p(self._trick_buf(tricks)), self._p(ob),
-                                            K.AUTO_RESET if auto_reset else 0, self._stream()))
+                                            (K.AUTO_RESET if auto_reset else 0) | (K.REWARD_REF if reward_ref else 0),
+                                            self._stream()))
         return Obs(ob), rw, dn
 
     def sample_policy(self, logits, obs_words, action_out=None, logp_out=None):
@@ -255,6 +260,59 @@ class TarokVecEnv:
                 out = torch.empty((self.n, 256), dtype=torch.bfloat16, device=self.device)
             _native.check(self.L.tarok_observe(self._h, self._p(out), self._stream()))
         return out
+
+    def observe_ref(self, out=None, meta=None):
+        """The reference's own observation layout for the seat to move (tarok_observe_ref;
+        Igralec.py:453-533).  Returns (record [N, REF_RECORD_BYTES] u8, meta [N,4] i32 = T, type, rows
+        used, seat); `ref_views` slices the record into the reference's tensors."""
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((self.n, K.REF_RECORD_BYTES), dtype=torch.uint8, device=self.device)
+            if meta is None:
+                meta = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            _native.check(self.L.tarok_observe_ref(self._h, self._p(out), self._p(meta), self._stream()))
+        return out, meta
+
+    @staticmethod
+    def ref_views(record):
+        """[N, REF_RECORD_BYTES] record -> dict of views named as in Igralec.py:455-519."""
+        n = record.shape[0]
+        cut = lambda a, b: record[:, a:b]
+        return {"input_layer_nasprotiki": cut(K.REF_OPP, K.REF_OWN).reshape(n, K.REF_ROWS, 3, 54),
+                "roka_input": cut(K.REF_OWN, K.REF_TALON).reshape(n, K.REF_ROWS, 54),
+                "talon_input": cut(K.REF_TALON, K.REF_KING).reshape(n, 6, 55),
+                "talon_input_klop": cut(K.REF_TALON, K.REF_TALON + 54),
+                "barva_kralja": cut(K.REF_KING, K.REF_INDEX), "index_tistega_ki_igra": cut(K.REF_INDEX, K.REF_DISCARDS),
+                "zalozil": cut(K.REF_DISCARDS, K.REF_LEGAL), "mozne_vec": cut(K.REF_LEGAL, K.REF_LEGAL + 54)}
+
+    def observe_exchange_ref(self, out=None):
+        """menjaj_talon_v_vektor (Igralec.py:535-543) for the games waiting for the exchange:
+        [N, REF_EXCHANGE_BYTES] u8 = roka 54 | talon (54,6) | igra 15 | pad."""
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((self.n, K.REF_EXCHANGE_BYTES), dtype=torch.uint8, device=self.device)
+            _native.check(self.L.tarok_observe_exchange_ref(self._h, self._p(out), self._stream()))
+        return out
+
+    def observe_hands_ref(self, out=None):
+        """The bidding input (Igralec.py:278-281): [N,4,54] u8, every seat's hand one-hot."""
+        with torch.cuda.device(self.device):
+            if out is None:
+                out = torch.empty((self.n, 4, 54), dtype=torch.uint8, device=self.device)
+            _native.check(self.L.tarok_observe_hands_ref(self._h, self._p(out), self._stream()))
+        return out
+
+    def get_history(self):
+        """[48,N] u8 device tensor: card p of every slot's current game (TarokVecEnv(history=True))."""
+        with torch.cuda.device(self.device):
+            h = torch.empty((48, self.n), dtype=torch.uint8, device=self.device)
+            _native.check(self.L.tarok_get_history(self._h, self._p(h), self._stream()))
+        return h
+
+    def set_history(self, hist):
+        h = self._dev(hist, torch.uint8, (48, self.n))
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_set_history(self._h, self._p(h), self._stream()))
 
     @staticmethod
     def mfma_weight_order(weight):

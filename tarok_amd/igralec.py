@@ -16,10 +16,18 @@ A reference-shaped agent (one that implements the callbacks) can be passed to `T
 unchanged.  It is the compatibility surface, not the fast one: the callbacks are per-game
 Python calls.  Agents that want throughput talk to `TarokVecEnv` in batches.
 
-Deviation, on purpose: a Solo_brez game is driven in the same phase as every other game.
-(In the reference it runs one `next()` ahead of the scheduler because its generator skips
-the 'Pripravljen menjat' yield, Navadna_igra.py:48,67-68 — invisible to players that key
-their state by game id.)
+Call order.  Within every game the callbacks arrive in the reference's order, and so do the batch
+barriers (`predict_*`) between them — pinned by the call log recorded from the reference's own
+`Tarok.paralel_start` (tests/golden/paralel_v1.npz `calls`,
+test_paralel_start_adapter_matches_reference_run).  Two differences, both on purpose:
+  * ACROSS games the interleaving follows the batch: the cards of all games are collected
+    (`igraj_karto` of game 0, 1, 2 ...), the device steps them together, then the results are handed
+    out game by game; the reference finishes `igraj_karto -> rezultat_* -> pripravi_igraj_karto` of one
+    game before it touches the next (Tarok.py:52-56).  A player that keys its state by game id — every
+    player of the reference does — cannot tell.
+  * a Solo_brez game is driven in the same phase as every other game.  In the reference it runs one
+    `next()` ahead of the scheduler because its generator skips the 'Pripravljen menjat' yield
+    (Navadna_igra.py:48,67-68): its callbacks come in the same order, but one batch barrier early.
 """
 import random
 import warnings
@@ -278,13 +286,12 @@ class Tarok:
         else:
             deals = np.asarray(self.deals, np.uint8)
         talon = [[Karta.iz_id(c) for c in deals[g, 48:54]] for g in range(n)]
-        for g in range(n):
-            for s, p in enumerate(seats[g]):
+        for g in range(n):                                                               # Tarok.py:36-38, one game at a time:
+            for s, p in enumerate(seats[g]):                                              # Igra.razdeli (Igra.py:68-72) ...
                 p.nova_igra(Roka([Karta.iz_id(c) for c in deals[g, 12 * s:12 * s + 12]]), seats[g], g)
-        # --- bidding (Igra.licitacija, Igra.py:75-114), batch barrier 1 (Tarok.py:38-40)
-        for g in range(n):
-            for p in seats[g]:
+            for p in seats[g]:                                                            # ... then Igra.licitacija's first lines (Igra.py:77-79)
                 _call(p, "pripavi_licitiram", g)
+        # --- bidding (Igra.licitacija, Igra.py:75-114), batch barrier 1 (Tarok.py:38-40)
         for p in self.igralci:
             _call(p, "predict_licitiram")
         contract = np.zeros(n, np.int8)

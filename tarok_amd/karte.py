@@ -41,6 +41,15 @@ MIX_FIXED = 16
 DEFER_EXCHANGE = 1
 AUTO_RESET = 2
 CLEAR_COUNTERS = 4
+REWARD_REF = 8           # step: reward_out = what rezultat_igre folds into the last transition (Igralec.py:421-437)
+HISTORY = 16             # TarokVecEnv(history=True): keep the play history (needed by observe_ref)
+
+# the reference-layout observation record (include/tarok_env.h TAROK_REF_*)
+REF_ROWS = 56
+REF_OPP, REF_OWN, REF_TALON, REF_KING, REF_INDEX, REF_DISCARDS, REF_LEGAL = 0, 9072, 12096, 12426, 12430, 12434, 12488
+REF_RECORD_BYTES = 12544
+REF_EXCHANGE_BYTES = 400
+REF_TYPES = ("Klop", "Navadna_igra", "Solo", "Berac")    # meta[:, 1] (Nevronski_igralec.Tipi_NN, Igralec.py:174-178)
 
 # observation word
 OBS_MASK = DECK

@@ -406,6 +406,41 @@ class _SpecPlayer:
         self.shared.setdefault("scores", {}).setdefault(g, {})[self.ime] = int(pts)
 
 
+# the player protocol's callbacks (Igralec.py:32-122) and where each carries the game id (oracle/gen_golden.py logs
+# the reference's run with the same table)
+_CALLBACKS = ["nova_igra", "pripavi_licitiram", "predict_licitiram", "licitiram", "izberi_barvo_kralja", "konec_licitiranja",
+              "pripravi_izbral_iz_talona", "predict_izberi_iz_talona", "menjaj_iz_talona", "izbral_iz_talona",
+              "poglej_karte_odprtega_beraca", "pripravi_igraj_karto", "predict_igraj_karto", "igraj_karto", "rezultat_stiha",
+              "rezultat_igre"]
+_ID_ARG = [2, 0, -1, 1, 0, 2, 2, -1, 2, 2, 1, 3, -1, 3, 2, 2]
+
+
+def _logged(cls, log):
+    """cls with every protocol callback logging (name, game id or -1, player) before it runs; callbacks the class
+    does not define are added as no-ops, so the log holds every call the scheduler makes."""
+    def wrap(name, k):
+        inner = getattr(cls, name, None)
+
+        def f(self, *a, **kw):
+            log.append((name, -1 if _ID_ARG[k] < 0 else int(a[_ID_ARG[k]]), int(self.ime)))
+            return inner(self, *a, **kw) if inner is not None else None
+        return f
+    return type("Logged" + cls.__name__, (cls,), {name: wrap(name, k) for k, name in enumerate(_CALLBACKS)})
+
+
+def _per_game(log, g):
+    """The calls that concern game g — its own callbacks as (name, seat-independent player) and the batch barriers as
+    (name, -1), one entry per barrier (the four players' predict_* calls collapsed) — up to its rezultat_igre."""
+    seq = []
+    for name, gid, p in log:
+        if gid == g:
+            seq.append((name, p))
+        elif gid == -1 and (not seq or seq[-1] != (name, -1)):
+            seq.append((name, -1))
+    last = max(k for k, x in enumerate(seq) if x[0] == "rezultat_igre")
+    return seq[:last + 1]
+
+
 def test_paralel_start_adapter_matches_reference_run(T, S, golden_dir):
     """tarok_amd.igralec.Tarok.paralel_start (callbacks served from the GPU env) against the
     reference's own Tarok.paralel_start on the same deals, bids and card choices."""
@@ -413,7 +448,8 @@ def test_paralel_start_adapter_matches_reference_run(T, S, golden_dir):
     ref = dict(np.load(os.path.join(golden_dir, "paralel_v1.npz")))
     n, seed, mix = len(ref["deals"]), int(ref["seed"]), int(ref["mix"])
     shared = {}
-    players = [_SpecPlayer(i, S, seed, mix, shared) for i in range(4)]
+    log = []
+    players = [_logged(_SpecPlayer, log)(i, S, seed, mix, shared) for i in range(4)]
     t = I.Tarok(players, n, seed=seed)
     rez = t.paralel_start()
     assert [rez[p] for p in players] == [int(x) for x in ref["totals"]]
@@ -423,6 +459,26 @@ def test_paralel_start_adapter_matches_reference_run(T, S, golden_dir):
         assert (c // 10, d) == (int(ref["setup"][g][0]), int(ref["setup"][g][1])), g
         if c == 0:      # Klop: tricks 1-6 carry the talon card (Klop.py:67-71)
             assert shared["tricks"][g] == [5] * 6 + [4] * 6
+    # ---- the ORDER of the callbacks, against the log recorded from the reference's own scheduler and
+    # engines (gen_golden.py: every protocol callback of Tarok.paralel_start's run, in call order)
+    names = [str(x) for x in ref["call_names"]]
+    assert names == _CALLBACKS
+    ref_log = [(names[k], int(g), int(p)) for k, g, p in ref["calls"]]
+    assert len(log) > 10000 and sorted(ref_log) == sorted(log)          # the same calls were made ...
+    solo_brez = [g for g in range(n) if int(ref["setup"][g][0]) == 8]
+    assert solo_brez, "the fixture holds Solo_brez games"
+    for g in range(n):                                                   # ... and, game by game, in the same order
+        mine, theirs = _per_game(log, g), _per_game(ref_log, g)
+        if g in solo_brez:
+            # the one expected difference (Navadna_igra.py:48,67-68: no 'Pripravljen menjat' yield, the game runs
+            # one next() ahead of Tarok.paralel_start): same callbacks in the same order, one barrier early
+            strip = lambda seq: [x for x in seq if x[1] >= 0]
+            assert strip(mine) == strip(theirs), g
+            first = lambda seq: next(k for k, x in enumerate(seq) if x[0] == "pripravi_igraj_karto")
+            barrier = ("predict_izberi_iz_talona", -1)
+            assert barrier in theirs[first(theirs):] and barrier not in mine[first(mine):] and barrier in mine[:first(mine)]
+        else:
+            assert mine == theirs, (g, int(ref["setup"][g][0]), next((k, a, b) for k, (a, b) in enumerate(zip(mine, theirs)) if a != b) if len(mine) == len(theirs) else (len(mine), len(theirs)))
 
 
 def test_paralel_start_with_bot_players(T):
@@ -490,6 +546,56 @@ def test_selfplay_iteration_runs_and_learns_something_finite(T, S):
         assert not env.legal_actions().error.any().item()      # the sampled cards were always legal
         st = sp.iterate(T=48, epochs=1, minibatches=4)           # graph replay
         assert np.isfinite(st["loss"]) and st["env_errors"] == 0
+    env.close()
+
+
+def test_selfplay_65536_envs_vs_oracle_replay(T, O, S):
+    """BASELINE config 4 at its size: SelfPlay on 65,536 envs with the fused MFMA policy, two iterations
+    (graph capture, then replay).  The second rollout's recorded cards are replayed on the CPU oracle for a
+    1-in-64 sample of the slots, from the env state at the rollout's start: every sampled card is legal,
+    every observation word, done flag and score equals the oracle's, through the auto-resets (next game =
+    episode + 1 of the slot), and the env's episode numbers / score sums moved by exactly that."""
+    import torch
+    from tarok_amd import selfplay as SP
+    n, seed, Tn = 65536, 21, 48
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    sp = SP.SelfPlay(env, hidden=256, seed=0)
+    st = sp.iterate(T=Tn, epochs=1, minibatches=8)               # warm-up launches + graph capture + first replay
+    assert st["env_errors"] == 0 and np.isfinite(st["loss"])
+    torch.cuda.synchronize()
+    lanes0 = env.state()
+    ep0, ss0 = env.counters()
+    words0 = sp.obs_words.cpu().numpy().view(np.uint64)
+    st = sp.iterate(T=Tn, epochs=1, minibatches=8)               # pure graph replay
+    assert st["env_errors"] == 0 and np.isfinite(st["loss"]) and st["rollout_steps_per_s"] > 0
+    buf = sp._buf
+    act = buf["act"].cpu().numpy()
+    done = buf["done"].cpu().numpy().astype(bool)
+    reward = buf["reward"].cpu().numpy()
+    words = buf["words"].cpu().numpy().view(np.uint64)
+    ep1, ss1 = env.counters()
+    lanes1 = env.state()
+    assert (words[0] == words0).all()
+    legal_ok = ((words[:Tn] >> act.astype(np.uint64)) & np.uint64(1)).astype(bool)
+    assert legal_ok.all()                                        # all 3.1 M sampled cards lie in their legal masks
+    for i in range(0, n, 64):
+        g = O.Game.from_lanes(lanes0[:, i])
+        ep = int(ep0[i])
+        ssum = ss0[i].astype(np.int64).copy()
+        assert g.obs_word() == int(words[0, i]) & ~(1 << 62), i
+        for t in range(Tn):
+            assert g.step(int(act[t, i])) >= 0, ("illegal card", i, t)
+            fin = g.done
+            assert bool(done[t, i]) == fin, (i, t)
+            if fin:
+                assert reward[t, i].tolist() == g.scores, (i, t)
+                ssum += np.array(g.scores)
+                ep += 1
+                g = O.Game.synth(seed, i, ep, S.MIX_ALL)
+            assert g.obs_word(fin) == int(words[t + 1, i]), (i, t)
+        assert ep == int(ep1[i]) and (ssum == ss1[i]).all(), i
+        assert (g.lanes() == lanes1[:, i]).all(), i
+    del sp
     env.close()
 
 
