@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define TAROK_ABI_VERSION 3
+#define TAROK_MAX_CARDS_PER_LAUNCH 192 /* tarok_krog_random / tarok_run_random: cards of every game per launch */
 
 #define TAROK_OK 0
 #define TAROK_EINVAL (-1) /* bad argument                                  */

@@ -238,6 +238,15 @@ __device__ __forceinline__ u64 score_game(const Game &g) {
     return pack_scores(s0, s1, s2, s3);
 }
 
+// Berac / Odprti_berac at its end (Berac.py:33-44): the declarer took the last trick played (he leads next:
+// apply_step has already made the winner the leader) -> -70 / -90, otherwise twelve tricks went by -> +70 / +90.
+__device__ __forceinline__ u64 berac_scores(const Game &g) {
+    int v = g.contract == TK_BERAC ? 70 : 90;
+    int sc = g.leader == g.declarer ? -v : v;
+    u32 d = g.declarer;
+    return pack_scores(d == 0 ? sc : 0, d == 1 ? sc : 0, d == 2 ? sc : 0, d == 3 ? sc : 0);
+}
+
 // One card: the body of krog (Klop.py:47-79, Navadna_igra.py:115-141) after
 // igraj_karto returned card `a`, then the per-contract loop bookkeeping
 // (Klop.py:27-45, Berac.py:26-44, Navadna_igra.py:72-113).
@@ -245,8 +254,11 @@ __device__ __forceinline__ u64 score_game(const Game &g) {
 // -1 = not a legal card: nothing changes except the error bit.
 // TRUSTED: `a` was drawn from the legal mask by the in-kernel policy, the membership test
 // (Klop.py:57-60, Navadna_igra.py:125-126) cannot fail and is skipped.
-template <bool TRUSTED = false>
-__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info) {
+// DEFER: a finished game's scores are NOT computed here (scores stays untouched): the caller keeps the
+// final state and calls final_scores() on it later (k_play scores the finished games of several tricks
+// together, on dense lanes).  want_tv = false skips the trick value (nobody asked for trick_info).
+template <bool TRUSTED = false, bool DEFER = false>
+__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info, bool want_tv = true) {
     if (!TRUSTED) {
         u64 legal = legal_now(g);
         bool ok = a < 54 && ((legal >> (a & 63)) & 1);
@@ -257,20 +269,16 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
     g.trick |= a << (6 * g.nt);
     g.nt++;
     if (g.nt < 4) return 0;
-    // pobere_stih / primerjaj_karti (Klop.py:81-94)
+    // pobere_stih / primerjaj_karti (Klop.py:81-94).  The running-best rule there — a challenger wins with a
+    // higher card of the best card's suit, or as a tarok against a non-tarok — makes the winner the highest tarok
+    // of the trick if one was played, else the highest card of the suit led (a card of any other suit never
+    // becomes the best one): read off the trick's card mask instead of three dependent comparisons.
     u32 c0 = g.trick & 63, c1 = (g.trick >> 6) & 63, c2 = (g.trick >> 12) & 63, c3 = (g.trick >> 18) & 63;
-    u32 w = 0, cw = c0;
-#define TK_CHALLENGE(ci, i)                                          \
-    {                                                                \
-        u32 sw = min(cw >> 3, 4u), si = min((ci) >> 3, 4u);          \
-        bool beats = (sw == si) ? (cw < (ci)) : (si == 4);           \
-        w = beats ? (i) : w;                                         \
-        cw = beats ? (ci) : cw;                                      \
-    }
-    TK_CHALLENGE(c1, 1u) TK_CHALLENGE(c2, 2u) TK_CHALLENGE(c3, 3u)
-#undef TK_CHALLENGE
-    u32 ws = (g.leader + w) & 3;
     u64 tm = (1ULL << c0) | (1ULL << c1) | (1ULL << c2) | (1ULL << c3);
+    u32 th = TK_HI(tm), tl_ = TK_LO(tm) & (0xFFu << (c0 & 24));          // taroks played; cards of the suit led
+    u32 cw = th ? 63u - (u32)__clz(th) : 31u - (u32)__clz(tl_);           // (a tarok lead: th != 0, tl_ is not looked at)
+    u32 w = c1 == cw ? 1u : (c2 == cw ? 2u : (c3 == cw ? 3u : 0u));
+    u32 ws = (g.leader + w) & 3;
     if (g.contract == TK_KLOP && g.tl > 0) {                              // talon gift, Klop.py:67-71
         g.tl--;
         tm |= 1ULL << ((g.talon >> (6 * g.tl)) & 63);
@@ -282,24 +290,26 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
     }
     // what rezultat_stiha(stih, sem_pobral) is told (Klop.py:76-77, Navadna_igra.py:138-139):
     // Roka.vrednost_stiha of the 4 (Klop: 5) cards (Roka.py:76-95) and who took them
-    u32 tv = (u32)(popc64(tm) + popc64(tm & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + popc64(tm & (TK_V3 | TK_V4 | TK_V5)) +
-                   popc64(tm & (TK_V4 | TK_V5)) + popc64(tm & TK_V5)) - 2;
-    trick_info = 0x8000u | (tv << 4) | ws;
-    g.leader = ws; g.nt = 0; g.trick = 0; g.trick_no++;
-    if (g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC) {
-        int v = g.contract == TK_BERAC ? 70 : 90;
-        bool lost = ws == g.declarer;                                     // Berac.py:33-39
-        if (!lost && g.trick_no < 12) return 0;
-        int sc = lost ? -v : v;
-        u32 d = g.declarer;
-        scores = pack_scores(d == 0 ? sc : 0, d == 1 ? sc : 0, d == 2 ? sc : 0, d == 3 ? sc : 0);
-        g.phase = TK_PHASE_DONE;
-        return 1;
+    if (want_tv) {
+        u32 tv = (u32)(popc64(tm) + popc64(tm & (TK_V2 | TK_V3 | TK_V4 | TK_V5)) + popc64(tm & (TK_V3 | TK_V4 | TK_V5)) +
+                       popc64(tm & (TK_V4 | TK_V5)) + popc64(tm & TK_V5)) - 2;
+        trick_info = 0x8000u | (tv << 4) | ws;
     }
-    if (g.trick_no < 12) return 0;
-    scores = score_game(g);
-    g.phase = TK_PHASE_DONE;
-    return 1;
+    g.leader = ws; g.nt = 0; g.trick = 0; g.trick_no++;
+    // the game is over after twelve tricks, a Berac also the moment the declarer takes a trick (Berac.py:33-39);
+    // straight-line selects: lanes of one wave sit in every combination of these cases
+    bool berac = ((0x280u >> g.contract) & 1u) != 0;                      // TK_BERAC = 7, TK_ODPRTI_BERAC = 9
+    bool over = g.trick_no >= 12 || (berac && ws == g.declarer);
+    if (!DEFER) {
+        if (over) scores = berac ? berac_scores(g) : score_game(g);
+    }
+    g.phase = over ? (u32)TK_PHASE_DONE : g.phase;
+    return over ? 1 : 0;
+}
+
+// The scores of a game that apply_step has just finished, from its final state alone.
+__device__ __forceinline__ u64 final_scores(const Game &g) {
+    return (g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC) ? berac_scores(g) : score_game(g);
 }
 
 // Igra.razdeli's result + engine constructor (Igra.py:38-55,65-73;

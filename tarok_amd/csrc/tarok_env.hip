@@ -43,6 +43,7 @@
 #define TK_AHEAD 7                  // next-game lines per slot (<= 7: epar and cprev are 3 bits each)
 #endif
 #define TK_LINE(episode) ((u32)(episode) % (u32)TK_AHEAD)
+#define TK_FINQ 128                 // entries of a play wave's finished-games ring (a power of two >= 128)
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 
@@ -338,6 +339,14 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     }
 }
 
+// LDS of the deferred scoring (play_role): allocated only in the kernels that use it
+template <bool D> __device__ __forceinline__ u32 (*finq_storage())[9][TK_FINQ] {
+    if constexpr (D) { __shared__ u32 q[TK_BLOCK / 64][9][TK_FINQ]; return q; } else return nullptr;
+}
+template <bool D> __device__ __forceinline__ int (*sacc_storage())[TK_BLOCK] {
+    if constexpr (D) { __shared__ int a[4][TK_BLOCK]; return a; } else return nullptr;
+}
+
 // Play role of a step launch for the 256 slots of play workgroup `group`: thread `tid` (0..255)
 // plays slot group * 256 + tid; threads with active = false (a larger workgroup's extra threads)
 // only take part in the two barriers.  The card comes from action_in, or (action_in == NULL) from
@@ -352,8 +361,50 @@ __device__ __forceinline__ void play_role(
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
     __shared__ u64 push_list[TK_REFILL_CAP];
     __shared__ u32 push_count;
+    // Deferred scoring (the multi-card kernel): a game that ends leaves its final state in a per-wave LDS ring
+    // (9 dwords) instead of being scored on the spot — with ~10 % of the slots finishing per trick the
+    // scoring code (both contract families, ~250 instructions) ran for every wave on every trick with 7 of 64
+    // lanes active: a third of a play wave's time at 65,536 games (tools/card_probe.py).  Whenever 64 entries
+    // wait they are scored in ONE pass on full lanes (drain_finished); the rest at the end of the launch.  The
+    // scores go to their reward row from there and are summed per slot in LDS (sacc) for the slot's score_sum.
+    constexpr bool DEFER = RANDOM;
+    u32 (*finq)[9][TK_FINQ] = finq_storage<DEFER>();
+    int (*sacc)[TK_BLOCK] = sacc_storage<DEFER>();
     if (tid == 0) push_count = 0;
+    if constexpr (DEFER) { sacc[0][tid] = 0; sacc[1][tid] = 0; sacc[2][tid] = 0; sacc[3][tid] = 0; }
     __syncthreads();
+    u32 fq_head = 0, fq_n = 0;               // this wave's ring: first waiting entry, entries waiting (wave uniform)
+    u32 (*fq)[TK_FINQ] = DEFER ? finq[tid >> 6] : nullptr;
+    // score `cnt_` waiting entries (at most 64) of the wave's ring on dense lanes
+    auto drain_finished = [&](u32 cnt_) __attribute__((always_inline)) {
+        u32 lane = tid & 63;
+        if (DEFER && lane < cnt_) {
+            u32 e = (fq_head + lane) & (TK_FINQ - 1);
+            Game f;
+            f.A = TK_U64(fq[0][e], fq[1][e]); f.B = TK_U64(fq[2][e], fq[3][e]); f.C = TK_U64(fq[4][e], fq[5][e]);
+            u32 m = fq[7][e], ri = fq[8][e];
+            f.talon = TK_U64(fq[6][e], (m >> 24) & 15u);
+            f.contract = m & 15; f.declarer = (m >> 4) & 3; f.king = (m >> 6) & 3; f.team = (m >> 8) & 15;
+            f.tl = (m >> 12) & 7; f.trick_no = (m >> 16) & 15; f.leader = (m >> 20) & 3;
+            f.trick = 0; f.nt = 0; f.phase = TK_PHASE_DONE; f.error = 0; f.epar = 0; f.cprev = 0;
+            u64 sc = final_scores(f);
+            u32 t = ri & 0xFFFFu;
+            if (reward) {
+                u64 rs = sc;
+                if ((flags & TAROK_REWARD_REF) && (f.contract == TK_BERAC || f.contract == TK_ODPRTI_BERAC)) {
+                    int dv = f.trick_no >= 12 ? -20 : 20;                  // Igralec.py:434-437 (see the immediate path below)
+                    u32 d = f.declarer;
+                    rs = pack_scores(d == 0 ? (int)(int16_t)(sc & 0xFFFF) : dv, d == 1 ? (int)(int16_t)((sc >> 16) & 0xFFFF) : dv,
+                                     d == 2 ? (int)(int16_t)((sc >> 32) & 0xFFFF) : dv, d == 3 ? (int)(int16_t)(sc >> 48) : dv);
+                }
+                reinterpret_cast<u64 *>(reward)[(int64_t)group * TK_BLOCK + t + (int64_t)(ri >> 16) * stride] = rs;
+            }
+            atomicAdd(&sacc[0][t], (int)(int16_t)(sc & 0xFFFF)); atomicAdd(&sacc[1][t], (int)(int16_t)((sc >> 16) & 0xFFFF));
+            atomicAdd(&sacc[2][t], (int)(int16_t)((sc >> 32) & 0xFFFF)); atomicAdd(&sacc[3][t], (int)(int16_t)(sc >> 48));
+        }
+        fq_head = (fq_head + cnt_) & (TK_FINQ - 1);
+        fq_n -= cnt_;
+    };
     u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
     if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
     int64_t i = (int64_t)group * TK_BLOCK + tid;
@@ -405,13 +456,16 @@ __device__ __forceinline__ void play_role(
 #ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
     u32 ev_deal = 0, ev_lazy = 0, ev_renew = 0;
 #endif
+#ifdef TK_CARD_STAMPS
+    u32 cs_012 = 0, cs_3 = 0;
+#endif
     bool resync = false;                    // a line that should have been usable was not: refill them all
     bool blocked = false;                   // a game was dealt in place: no more swap-ins in this launch
     bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
-    auto play_card = [&](auto all_tag, auto nt_tag, int64_t row) __attribute__((always_inline)) {
+    auto play_card = [&](auto all_tag, auto nt_tag, int64_t row, int ci) __attribute__((always_inline)) {
         // ALL: every lane of the wave is a valid slot with a game in play (wave uniform, see below):
         // no per-lane predicates around the rules and the output stores.
         // NT >= 0: moreover every lane is at card NT of its trick: the constant propagates through
@@ -429,7 +483,7 @@ __device__ __forceinline__ void play_role(
         const u32 pos = g.trick_no * 4 + g.nt;            // cards played so far in this game
         const u32 d_fin = g.declarer;
         const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-        if (play) res = RANDOM ? apply_step<true>(g, a, scores, trick_info) : apply_step<false>(g, a, scores, trick_info);
+        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, trick != nullptr) : apply_step<false, false>(g, a, scores, trick_info);
         bool fin = res == 1;
         // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
         // write-only here; only the reference-layout observation (k_observe_ref) reads it
@@ -442,7 +496,22 @@ __device__ __forceinline__ void play_role(
         }
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
-        if (CAN_END && fin) {
+        if constexpr (CAN_END && DEFER) {
+            u64 fm = __ballot(fin);
+            if (fm) {                                                     // (wave uniform)
+                if (fq_n >= 64) drain_finished(64);                       // room for 64 more: fewer than 64 wait now
+                if (fin) {
+                    u32 e = (fq_head + fq_n + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
+                    fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
+                    fq[4][e] = TK_LO(g.C); fq[5][e] = TK_HI(g.C); fq[6][e] = TK_LO(g.talon);
+                    fq[7][e] = g.contract | (g.declarer << 4) | (g.king << 6) | (g.team << 8) | (g.tl << 12) | (g.trick_no << 16) |
+                               (g.leader << 20) | (TK_HI(g.talon) << 24);
+                    fq[8][e] = ((u32)ci << 16) | tid;
+                }
+                fq_n += (u32)__popcll(fm);
+            }
+        }
+        if (CAN_END && !DEFER && fin) {
             if (reward) {
                 u64 rs = scores;
                 if ((flags & TAROK_REWARD_REF) && berac_fin) {
@@ -531,20 +600,36 @@ __device__ __forceinline__ void play_role(
     if (autoreset && __ballot(valid && g.phase == TK_PHASE_PLAY) == ~0ULL) {
         if ((cards & 3) == 0 && __ballot(g.nt != 0) == 0) {
             for (int c = 0; c < cards; c += 4) {
-                play_card(std::true_type{}, std::integral_constant<int, 0>{}, row); row += stride;
-                play_card(std::true_type{}, std::integral_constant<int, 1>{}, row); row += stride;
-                play_card(std::true_type{}, std::integral_constant<int, 2>{}, row); row += stride;
-                play_card(std::true_type{}, std::integral_constant<int, 3>{}, row); row += stride;
+#ifdef TK_CARD_STAMPS                       // diagnostics build (tools/card_probe.py): cycles of cards 0-2 vs the trick's 4th card
+                u64 ts_a = __builtin_amdgcn_s_memtime();
+#endif
+                play_card(std::true_type{}, std::integral_constant<int, 0>{}, row, c); row += stride;
+                play_card(std::true_type{}, std::integral_constant<int, 1>{}, row, c + 1); row += stride;
+                play_card(std::true_type{}, std::integral_constant<int, 2>{}, row, c + 2); row += stride;
+#ifdef TK_CARD_STAMPS
+                u64 ts_b = __builtin_amdgcn_s_memtime();
+#endif
+                play_card(std::true_type{}, std::integral_constant<int, 3>{}, row, c + 3); row += stride;
+#ifdef TK_CARD_STAMPS
+                u64 ts_c = __builtin_amdgcn_s_memtime();
+                cs_012 += (u32)(ts_b - ts_a); cs_3 += (u32)(ts_c - ts_b);
+#endif
             }
         } else {
-            for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, row);
+            for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, row, c);
         }
     } else {
-        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, row);
+        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, row, c);
     }
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+TK_AHEAD.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
     // a game dealt in place: all of them.
+    if constexpr (DEFER) {
+        while (fq_n) drain_finished(min(fq_n, 64u));                      // (at most two passes: fewer than 128 wait)
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               // the wave's LDS adds have landed (lgkmcnt(0))
+        int4 sa = make_int4(sacc[0][tid], sacc[1][tid], sacc[2][tid], sacc[3][tid]);
+        if (sa.x | sa.y | sa.z | sa.w) { acc.x += sa.x; acc.y += sa.y; acc.z += sa.z; acc.w += sa.w; acc_dirty = true; }
+    }
     u32 np = resync ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
     if (valid) {
         g.cprev = np;                        // the next launch must not read those lines
@@ -568,6 +653,9 @@ __device__ __forceinline__ void play_role(
         stamps[3 * w + 0] = t_real0;
         stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
         stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
+#ifdef TK_CARD_STAMPS
+        stamps[3 * w + 0] = ((u64)cs_012 << 32) | (u64)cs_3;
+#endif
 #ifdef TK_EVENT_STAMPS                      // (replaces the entry time stamp)
         stamps[3 * w + 0] = ((u64)ev_deal << 48) | ((u64)ev_lazy << 32) | ((u64)ev_renew << 16) | (u64)__popcll(__ballot(consumed > 0));
 #endif
@@ -1732,7 +1820,7 @@ int tarok_step_random(tarok_env *e, uint8_t *action_out, int16_t *reward_out, ui
 
 int tarok_krog_random(tarok_env *e, int cards, int64_t stride, uint8_t *action_out, int16_t *reward_out,
                       uint8_t *done_out, uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream) {
-    if (!e || !obs_out || cards < 1 || cards > 48 || stride < e->n) return TAROK_EINVAL;
+    if (!e || !obs_out || cards < 1 || cards > TAROK_MAX_CARDS_PER_LAUNCH || stride < e->n) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     launch_play(e, true, cards, stride, nullptr, action_out, reward_out, done_out, trick_out, obs_out, flags,
                 (hipStream_t)stream);
@@ -1753,8 +1841,8 @@ static inline void launch_one(tarok_env *e, int cards, uint8_t *action, int16_t 
 
 int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int graph_chunk, int prefetch_every,
                      uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint64_t *obs_out, int flags, void *stream) {
-    if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 4096 || prefetch_every < 0) return TAROK_EINVAL;
-    if (cards_per_launch < 0 || cards_per_launch > 48) return TAROK_EINVAL;
+    if (!e || !obs_out || n_steps < 0 || graph_chunk < 0 || graph_chunk > 8192 || prefetch_every < 0) return TAROK_EINVAL;
+    if (cards_per_launch < 0 || cards_per_launch > TAROK_MAX_CARDS_PER_LAUNCH) return TAROK_EINVAL;
     int unit = cards_per_launch >= 2 ? cards_per_launch : 1;          // lock-steps per launch
     if (n_steps % unit != 0 || graph_chunk % unit != 0) return TAROK_EINVAL;
     if (prefetch_every % unit != 0) return TAROK_EINVAL;

@@ -11,6 +11,8 @@ using std::max;
 using std::min;
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+// v_ffbh_u32 as HIP's __clz: leading zeros, 32 for 0
+static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // v_bfe_u32: (src >> offset[4:0]) & ((1 << width[4:0]) - 1)
 static inline unsigned __builtin_amdgcn_ubfe(unsigned s, unsigned off, unsigned w) {
