@@ -172,11 +172,13 @@ __device__ __forceinline__ u64 legal_now(const Game &g) {
 }
 
 // observation word (tarok_env.h TAROK_OBS_*) from an already computed legal mask
+// (IN_PLAY: the caller knows that the game is not in the DONE phase)
+template <bool IN_PLAY = false>
 __device__ __forceinline__ u64 obs_word_with(const Game &g, bool finished_now, u64 legal) {
     u64 o = legal;
     o |= (u64)((g.leader + g.nt) & 3) << 54;
     o |= (u64)(g.trick_no * 4 + g.nt) << 56;
-    if (finished_now || g.phase == TK_PHASE_DONE) o |= 1ULL << 62;
+    if (finished_now || (!IN_PLAY && g.phase == TK_PHASE_DONE)) o |= 1ULL << 62;
     o |= (u64)g.error << 63;
     return o;
 }

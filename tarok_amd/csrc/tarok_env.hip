@@ -465,13 +465,16 @@ __device__ __forceinline__ void play_role(
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
-    auto play_card = [&](auto all_tag, auto nt_tag, int64_t row, int ci) __attribute__((always_inline)) {
+    auto play_card = [&](auto all_tag, auto nt_tag, auto std_tag, int64_t row, int ci) __attribute__((always_inline)) {
         // ALL: every lane of the wave is a valid slot with a game in play (wave uniform, see below):
         // no per-lane predicates around the rules and the output stores.
         // NT >= 0: moreover every lane is at card NT of its trick: the constant propagates through
         // the rules (no trick-end test on cards 0..2, constant shifts, "somebody led" known)
+        // STD: the usual set of outputs of a rollout — action_out and done given, trick not — known for the
+        // whole launch: no pointer tests per card (two scalar instructions each: as dear as vector ones here)
         constexpr bool ALL = decltype(all_tag)::value;
         constexpr int NT = decltype(nt_tag)::value;
+        constexpr bool STD = decltype(std_tag)::value;
         if constexpr (NT >= 0) g.nt = (u32)NT;
         const bool v = ALL ? true : valid;
         const bool play = ALL ? true : (valid && g.phase == TK_PHASE_PLAY);
@@ -483,7 +486,7 @@ __device__ __forceinline__ void play_role(
         const u32 pos = g.trick_no * 4 + g.nt;            // cards played so far in this game
         const u32 d_fin = g.declarer;
         const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, trick != nullptr) : apply_step<false, false>(g, a, scores, trick_info);
+        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, !STD && trick != nullptr) : apply_step<false, false>(g, a, scores, trick_info);
         bool fin = res == 1;
         // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
         // write-only here; only the reference-layout observation (k_observe_ref) reads it
@@ -491,8 +494,8 @@ __device__ __forceinline__ void play_role(
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
         if (v) {
-            if (RANDOM && action_out) action_out[row] = (uint8_t)a;
-            if (trick) trick[row] = (uint16_t)trick_info;
+            if (RANDOM && (STD || action_out)) action_out[row] = (uint8_t)a;
+            if (!STD && trick) trick[row] = (uint16_t)trick_info;
         }
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
@@ -527,8 +530,8 @@ __device__ __forceinline__ void play_role(
             acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
             acc_dirty = true;
         }
-        if (CAN_END && autoreset) {
-            bool renew = v && g.phase == TK_PHASE_DONE;
+        if (CAN_END && (ALL || autoreset)) {                 // (ALL implies auto-reset, and every lane was in play: done = just finished)
+            bool renew = ALL ? fin : (v && g.phase == TK_PHASE_DONE);
             if (__ballot(renew)) {
 #ifdef TK_EVENT_STAMPS
                 ev_renew++;
@@ -584,10 +587,11 @@ __device__ __forceinline__ void play_role(
                 if (renew) { cur_ep++; consumed++; seats_dirty = true; }
             }
         }
-        if (RANDOM) legal = (v && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+        // (ALL: a finished game has been replaced just above, so every lane is in play again)
+        if (RANDOM) legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
         if (v) {
-            obs[row] = RANDOM ? obs_word_with(g, fin, legal) : obs_word(g, fin);
-            if (done) done[row] = fin ? 1 : 0;
+            obs[row] = RANDOM ? obs_word_with<ALL>(g, fin, legal) : obs_word(g, fin);
+            if (STD || done) done[row] = fin ? 1 : 0;
         }
     };
     // With auto-reset a lane that is in play stays in play (a finished game is replaced within the
@@ -599,27 +603,31 @@ __device__ __forceinline__ void play_role(
     typedef std::integral_constant<int, -1> nt_any;
     if (autoreset && __ballot(valid && g.phase == TK_PHASE_PLAY) == ~0ULL) {
         if ((cards & 3) == 0 && __ballot(g.nt != 0) == 0) {
-            for (int c = 0; c < cards; c += 4) {
+            auto tricks = [&](auto std_tag) __attribute__((always_inline)) {
+                for (int c = 0; c < cards; c += 4) {
 #ifdef TK_CARD_STAMPS                       // diagnostics build (tools/card_probe.py): cycles of cards 0-2 vs the trick's 4th card
-                u64 ts_a = __builtin_amdgcn_s_memtime();
+                    u64 ts_a = __builtin_amdgcn_s_memtime();
 #endif
-                play_card(std::true_type{}, std::integral_constant<int, 0>{}, row, c); row += stride;
-                play_card(std::true_type{}, std::integral_constant<int, 1>{}, row, c + 1); row += stride;
-                play_card(std::true_type{}, std::integral_constant<int, 2>{}, row, c + 2); row += stride;
+                    play_card(std::true_type{}, std::integral_constant<int, 0>{}, std_tag, row, c); row += stride;
+                    play_card(std::true_type{}, std::integral_constant<int, 1>{}, std_tag, row, c + 1); row += stride;
+                    play_card(std::true_type{}, std::integral_constant<int, 2>{}, std_tag, row, c + 2); row += stride;
 #ifdef TK_CARD_STAMPS
-                u64 ts_b = __builtin_amdgcn_s_memtime();
+                    u64 ts_b = __builtin_amdgcn_s_memtime();
 #endif
-                play_card(std::true_type{}, std::integral_constant<int, 3>{}, row, c + 3); row += stride;
+                    play_card(std::true_type{}, std::integral_constant<int, 3>{}, std_tag, row, c + 3); row += stride;
 #ifdef TK_CARD_STAMPS
-                u64 ts_c = __builtin_amdgcn_s_memtime();
-                cs_012 += (u32)(ts_b - ts_a); cs_3 += (u32)(ts_c - ts_b);
+                    u64 ts_c = __builtin_amdgcn_s_memtime();
+                    cs_012 += (u32)(ts_b - ts_a); cs_3 += (u32)(ts_c - ts_b);
 #endif
-            }
+                }
+            };
+            if (RANDOM && action_out && done && !trick) tricks(std::true_type{});
+            else tricks(std::false_type{});
         } else {
-            for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, row, c);
+            for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, std::false_type{}, row, c);
         }
     } else {
-        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, row, c);
+        for (int c = 0; c < cards; c++, row += stride) play_card(std::false_type{}, nt_any{}, std::false_type{}, row, c);
     }
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+TK_AHEAD.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
