@@ -278,12 +278,16 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
     u32 c0 = g.trick & 63, c1 = (g.trick >> 6) & 63, c2 = (g.trick >> 12) & 63, c3 = (g.trick >> 18) & 63;
     u64 tm = (1ULL << c0) | (1ULL << c1) | (1ULL << c2) | (1ULL << c3);
     u32 th = TK_HI(tm), tl_ = TK_LO(tm) & (0xFFu << (c0 & 24));          // taroks played; cards of the suit led
-    u32 cw = th ? 63u - (u32)__clz(th) : 31u - (u32)__clz(tl_);           // (a tarok lead: th != 0, tl_ is not looked at)
+    // (the card led is a tarok or of its own suit: the chosen word is never zero; selects, no branches — a
+    // scalar branch costs a lone wave as much as a vector instruction)
+    u32 cw = (th ? 63u : 31u) - (u32)__builtin_clz(th ? th : tl_);
     u32 w = c1 == cw ? 1u : (c2 == cw ? 2u : (c3 == cw ? 3u : 0u));
     u32 ws = (g.leader + w) & 3;
-    if (g.contract == TK_KLOP && g.tl > 0) {                              // talon gift, Klop.py:67-71
-        g.tl--;
-        tm |= 1ULL << ((g.talon >> (6 * g.tl)) & 63);
+    {   // talon gift, Klop.py:67-71: talon.pop() joins the trick after the winner is known
+        bool gift = g.contract == TK_KLOP && g.tl > 0;
+        g.tl -= gift ? 1u : 0u;
+        u64 gb = 1ULL << ((u32)(g.talon >> (6 * g.tl)) & 63u);
+        tm |= gift ? gb : 0ULL;
     }
     {   // the trick's cards change owner: plane bit := winner's seat bit where tm is set (one bitop3 per half)
         u32 m1 = (u32)((int)(ws << 31) >> 31), m2 = (u32)((int)(ws << 30) >> 31);

@@ -93,6 +93,7 @@ struct tarok_env {
     u32 *epoch;              // [0] launch epoch (its low bit = parity of the refill list a launch writes; it works the
                              // other one off), [32] workgroups of the running launch that are done: two 128-byte lines
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
+    bool wide_regs;          // the 256-VGPR build of the multi-card kernel (batches of at most two play waves per SIMD)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -670,16 +671,20 @@ __device__ __forceinline__ void play_role(
     }
 }
 
-// (at most 128 VGPRs: four waves per SIMD for the throughput-bound batch sizes; the specialised
-// card loops would otherwise take 131)
-// HIST: also record the play history (one byte per card; tarok_create flag TAROK_HISTORY)
+// Two register budgets of the same kernel.  WIDE = false: at most 128 VGPRs, four waves per SIMD — the
+// throughput-bound batch sizes (the specialised card loops want a few more and spill a little).  WIDE = true:
+// up to 256 VGPRs, for batches that put no more than two play waves on a SIMD anyway (up to 131,072 games:
+// the BASELINE size has one) — nothing spills inside the card loops, where a scratch reload is a memory
+// round trip that nothing hides.  HIST: also record the play history (one byte per card; tarok_create flag
+// TAROK_HISTORY).
+#define TK_PLAY_ARGS                                                                                                             \
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,         \
+        const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
+        uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
+        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
+        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps
 template <bool RANDOM, bool HIST>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,
-    const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
-    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
+__device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
     u32 ep = launch_epoch(epoch), par = ep & 1u;
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
@@ -687,6 +692,16 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         play_role<RANDOM, HIST>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in,
                                 action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
     launch_done(epoch, ep);
+}
+#define TK_PLAY_FWD n, seed, offset, mix, flags, cards, stride, play_groups, epoch, fan, action_in, action_out, reward, done, trick, obs, \
+                    hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps
+template <bool RANDOM, bool HIST>
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(TK_PLAY_ARGS) {
+    play_kernel_body<RANDOM, HIST>(TK_PLAY_FWD);
+}
+template <bool RANDOM, bool HIST>
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_play_wide(TK_PLAY_ARGS) {
+    play_kernel_body<RANDOM, HIST>(TK_PLAY_FWD);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1691,6 +1706,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
+    e->wide_regs = n_games <= 2 * 1024 * 64;                  // 1,024 SIMDs x 64 lanes x 2 waves
+    if (const char *f = getenv("TAROK_WIDE_REGS")) e->wide_regs = atoi(f) != 0;      // diagnostics (A/B runs)
     if (const char *f = getenv("TAROK_REFILL_FAN")) { int v = atoi(f); if (v >= 1 && v <= TK_REFILL_FAN) e->refill_fan = (uint32_t)v; }
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
@@ -1789,13 +1806,14 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     // (the external-policy kernel always carries the history code: one uniform test of `hist` per launch)
-#define TK_LAUNCH_PLAY(R, H)                                                                                                \
-    hipLaunchKernelGGL((k_play<R, H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
-                       groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01,     \
+#define TK_LAUNCH_PLAY(K, R, H)                                                                                        \
+    hipLaunchKernelGGL((K<R, H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
+                       groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, \
                        e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, e->stamps)
-    if (!random) TK_LAUNCH_PLAY(false, true);
-    else if (e->hist) TK_LAUNCH_PLAY(true, true);
-    else TK_LAUNCH_PLAY(true, false);
+    bool wide = e->wide_regs;                                 // (see k_play_wide)
+    if (!random) TK_LAUNCH_PLAY(k_play, false, true);
+    else if (e->hist) { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, true); else TK_LAUNCH_PLAY(k_play, true, true); }
+    else { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, false); else TK_LAUNCH_PLAY(k_play, true, false); }
 #undef TK_LAUNCH_PLAY
 }
 
