@@ -44,6 +44,13 @@
 #endif
 #define TK_LINE(episode) ((u32)(episode) % (u32)TK_AHEAD)
 #define TK_FINQ 128                 // entries of a play wave's finished-games ring (a power of two >= 128)
+// The per-card outputs are written once and never read back by the kernels: non-temporal stores, so that
+// they stream out during the launch instead of piling up as dirty L2 lines for the write-back at its end
+#ifndef TK_NO_STREAM_STORES
+#define TK_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define TK_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#endif
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 
@@ -495,8 +502,8 @@ __device__ __forceinline__ void play_role(
         touched = touched || res != -2;
         seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
         if (v) {
-            if (RANDOM && (STD || action_out)) action_out[row] = (uint8_t)a;
-            if (!STD && trick) trick[row] = (uint16_t)trick_info;
+            if (RANDOM && (STD || action_out)) TK_STREAM_STORE(&action_out[row], (uint8_t)a);
+            if (!STD && trick) TK_STREAM_STORE(&trick[row], (uint16_t)trick_info);
         }
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
@@ -591,8 +598,8 @@ __device__ __forceinline__ void play_role(
         // (ALL: a finished game has been replaced just above, so every lane is in play again)
         if (RANDOM) legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
         if (v) {
-            obs[row] = RANDOM ? obs_word_with<ALL>(g, fin, legal) : obs_word(g, fin);
-            if (STD || done) done[row] = fin ? 1 : 0;
+            TK_STREAM_STORE(&obs[row], RANDOM ? obs_word_with<ALL>(g, fin, legal) : obs_word(g, fin));
+            if (STD || done) TK_STREAM_STORE(&done[row], (uint8_t)(fin ? 1 : 0));
         }
     };
     // With auto-reset a lane that is in play stays in play (a finished game is replaced within the
