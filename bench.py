@@ -299,23 +299,34 @@ def main():
                         "DESIGN.md has the N sweep)" % (n, n * 520 / 1e6, (n + 63) // 64))
         out["roofline"] = roof
 
-        # ---- what actually bounds the kernel: vector-instruction issue.  VALU instructions
-        # per step from the committed SQ counter passes (tools/sq_counters.sh), cycles per VALU instruction
-        # from the issue microbenchmark (tools/valu_issue.hip -> profiles/<tag>_valu_issue.json).
+        # ---- what actually bounds the kernel: instruction issue.  Instructions per step from
+        # the committed SQ counter passes of this command (tools/sq_counters.sh), issue costs from the
+        # microbenchmark (tools/valu_issue.hip -> profiles/<tag>_valu_issue.json): a wave that is alone on its
+        # SIMD issues one instruction of ANY kind per ~4.6 cycles; with two or more waves per SIMD the SIMD's
+        # own time per VALU instruction (full rate ~2.3, half rate ~4.2 cycles) is the limit.
         sq, sq_prov = load_profile("%s_sq_counters.json" % PROFILE_TAG, sha)
-        vi, _ = load_profile("%s_valu_issue.json" % PROFILE_TAG, sha)
-        if sq and vi and sq.get("cards_per_launch") == cards and "SQ_INSTS_VALU" in sq:
-            waves = sq["games"] / 64.0 * sq["cards_per_launch"]
-            per_step = sq["SQ_INSTS_VALU"]["mean"] / waves
-            cyc = vi["k_play_mix_cycles_per_valu"]            # measured, weighted by k_play's instruction mix
+        vi, vi_prov = load_profile("%s_valu_issue.json" % PROFILE_TAG, sha)
+        if sq and vi and sq.get("cards_per_launch") == cards and sq.get("games") == n and "SQ_INSTS_VALU" in sq:
+            wave_steps = sq["games"] / 64.0 * sq["cards_per_launch"]
+            valu = sq["SQ_INSTS_VALU"]["mean"] / wave_steps
+            every = sum(sq[k]["mean"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR",
+                                                "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if k in sq) / wave_steps
             clock = vi.get("clock_hz", 2.4e9)
-            ceiling = 1024 * clock / cyc * 64.0 / per_step
-            out["issue_roofline"] = {"bound": "valu issue", "valu_instructions_per_step": per_step,
-                                     "cycles_per_valu_instruction": cyc, "clock_hz": clock,
-                                     "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
-                                     "provenance": sq_prov, "issue_cost_source": "profiles/%s_valu_issue.json" % PROFILE_TAG,
-                                     "note": "1024 SIMDs x clock / measured cycles per wave64 VALU instruction x 64 lanes / "
-                                             "VALU instructions per step"}
+            simd_ceiling = 1024 * clock * 64.0 / (valu * vi["k_play_mix_cycles_per_valu"])
+            lone_ceiling = 1024 * clock * 64.0 / (every * vi["lone_wave_cycles_per_instruction"])
+            lone = (n + 63) // 64 <= 1024
+            ceiling = lone_ceiling if lone else simd_ceiling
+            out["issue_roofline"] = {
+                "bound": "instruction issue, one wave per SIMD" if lone else "SIMD time of the VALU instructions",
+                "valu_instructions_per_step": valu, "all_instructions_per_step": every,
+                "lone_wave_cycles_per_instruction": vi["lone_wave_cycles_per_instruction"],
+                "simd_cycles_per_valu_instruction_k_play_mix": vi["k_play_mix_cycles_per_valu"], "clock_hz": clock,
+                "ceiling_one_wave_per_simd": lone_ceiling, "ceiling_simd_throughput": simd_ceiling,
+                "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
+                "provenance": {"counters": sq_prov, "issue_costs": vi_prov},
+                "note": "instructions per step = SQ counters of a launch / (games / 64 x cards): the refill waves' deals are "
+                        "counted in, although they share SIMDs with the play waves only briefly, so the one-wave ceiling is an "
+                        "under-estimate; 1024 SIMDs x clock x 64 lanes / (instructions per step x cycles per instruction)"}
 
     if not args.no_extras:
         # ---- side measurements (not `value`); lock-steps per region = the headline's, capped

@@ -13,9 +13,9 @@
 // (sorting-network deals on dense lanes) while its own play workgroups run — the ~5 us of deal
 // latency overlaps the next launch instead of following this one.  Seven games ahead let a launch
 // play up to twelve tricks (the shortest game, a Berac lost on trick 1, is 4 cards) practically
-// without ever waiting for a deal.  Lists are double-buffered by launch parity — the low bit of a
-// launch epoch kept in DEVICE memory, advanced by the last workgroup of every step launch to finish
-// (launch_done), so eager launches and replays of captured graphs (the library's own or a caller's,
+// without ever waiting for a deal.  Lists are double-buffered by launch parity — kept in DEVICE memory
+// as a count of started workgroups that every step launch advances by its grid size (launch_count /
+// launch_counted), so eager launches and replays of captured graphs (the library's own or a caller's,
 // e.g. torch.cuda.graph) mix freely and in any number.  A line is valid iff its episode tag matches
 // and it is not being re-dealt right now (`cprev` in the slot's state), and a slot that ever runs
 // out of usable lines just deals the game itself, wave-cooperatively (ballot/readlane), same result.
@@ -97,8 +97,8 @@ struct tarok_env {
     uint8_t *hist;           // [48][n] play history (card p of the slot's current game), TAROK_HISTORY envs only
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
     u32 *rcount;             // [play workgroups][2]
-    u32 *epoch;              // [0] launch epoch (its low bit = parity of the refill list a launch writes; it works the
-                             // other one off), [32] workgroups of the running launch that are done: two 128-byte lines
+    u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
+                             // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
     bool wide_regs;          // the 256-VGPR build of the multi-card kernel (batches of at most two play waves per SIMD)
     u64 *stamps;             // diagnostics only
@@ -284,27 +284,28 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
     action[i] = (uint8_t)a;
 }
 
-// Launch epoch (see the file header).  Every workgroup of a step launch reads it when it starts
-// (its low bit = this launch's list parity); the workgroup that finishes last advances it for the
-// next launch.  Nothing writes the epoch while a workgroup of the launch can still read it: every
-// workgroup's read has completed (the barrier's s_waitcnt) before its own "done" count, and the
-// write follows the last such count.  Agent-scope atomics: the counter is shared by all XCDs.
-// RELAXED on purpose: the ordering needed inside the launch comes from the barrier and from the
-// counter's own modification order, and the next launch sees the new epoch through the kernel
-// boundary; an acquire/release pair here would write back and invalidate the L2 in every
-// workgroup (+11 us per launch when it was tried).
-__device__ __forceinline__ u32 launch_epoch(const u32 *epoch) {
-    return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Launch parity (see the file header) without a host counter.  The workgroups of step launches are counted
+// as they START, modulo twice their number G per launch (every step launch of an env has the same grid):
+// launch L begins with the count at (L mod 2) * G; every workgroup reads the count together with its first
+// loads (launch_count: nothing waits for it alone) and adds itself afterwards (launch_counted: a wrapping
+// increment WITHOUT a return value, issued once the read has returned — it completes somewhere under the
+// card loop).  At any read at most G - 1 workgroups of the running launch have added themselves, so the
+// count is still in launch L's half: parity = "count >= G".  The kernel boundary drains the adds before
+// the next launch reads.  The count is kept in TK_EPOCH_SHARDS separate counters (one 128-byte line each),
+// workgroup b using counter b mod TK_EPOCH_SHARDS with G_s = the number of such workgroups: the argument
+// holds for every counter on its own, and the adds do not queue up behind each other — ONE counter took
+// 512 same-address atomics per launch at 65,536 games, serialised at the memory side: +3.4 us on every
+// launch, wherever in the kernel they were issued (profiles/r02_ab_launch_parity.txt).
+#define TK_EPOCH_SHARDS 256
+__device__ __forceinline__ u32 launch_shard_size() {      // workgroups of this grid that share this workgroup's counter
+    return (gridDim.x + TK_EPOCH_SHARDS - 1 - (blockIdx.x % TK_EPOCH_SHARDS)) / TK_EPOCH_SHARDS;
 }
-__device__ __forceinline__ void launch_done(u32 *epoch, u32 ep) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 old = __hip_atomic_fetch_add(epoch + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == gridDim.x - 1) {
-            __hip_atomic_store(epoch + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(epoch, ep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+__device__ __forceinline__ u32 launch_count(const u32 *epoch) {
+    return __hip_atomic_load(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u32 launch_parity(u32 count) { return count >= launch_shard_size() ? 1u : 0u; }
+__device__ __forceinline__ void launch_counted(u32 *epoch) {          // call after launch_count's value has arrived
+    if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), 2u * launch_shard_size() - 1u);
 }
 
 // THE step kernel.  One launch plays `cards` cards of every game:
@@ -326,15 +327,25 @@ __device__ __forceinline__ void launch_done(u32 *epoch, u32 ep) {
 // workgroup), concatenated so that the sorting-network deals run on dense lanes (~11 % of the
 // slots of a group finish per trick: 8 lists fill a 256-thread workgroup).  Small batches use a
 // smaller fan: a refill workgroup that needs a second pass would outlast the play.
+// `count` = launch_count()'s value, possibly still in flight: the list lengths of BOTH parities are requested
+// before it is looked at, so the parity costs this role no memory round trip of its own.
 __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
-                                        u32 par, u32 fan, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
+                                        u32 count, u32 *epoch, u32 fan, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
                                         const u32 *__restrict__ rcount) {
     u32 g0 = rblock * fan;
+    u32 len[2][TK_REFILL_FAN];
+#pragma unroll
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) {
+        bool has = q < fan && g0 + q < play_groups;
+        len[0][q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
+        len[1][q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
+    }
+    u32 par = launch_parity(count);
+    launch_counted(epoch);
     u32 cum[TK_REFILL_FAN + 1];
     cum[0] = 0;
 #pragma unroll
-    for (u32 q = 0; q < TK_REFILL_FAN; q++)
-        cum[q + 1] = cum[q] + ((q < fan && g0 + q < play_groups) ? rcount[TK_RC(g0 + q, par ^ 1)] : 0u);
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + (par ? len[0][q] : len[1][q]);
     for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
         u32 q = 0;
 #pragma unroll
@@ -362,7 +373,7 @@ template <bool D> __device__ __forceinline__ int (*sacc_storage())[TK_BLOCK] {
 template <bool RANDOM, bool HIST>
 __device__ __forceinline__ void play_role(
     u32 group, u32 tid, bool active, u32 a_reg,
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 par,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 count, u32 *epoch,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
@@ -459,6 +470,8 @@ __device__ __forceinline__ void play_role(
         }
     }
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
+    u32 par = launch_parity(count);         // (`count` was requested before the state: it has arrived with it)
+    if (epoch) launch_counted(epoch);
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
 #ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
@@ -692,13 +705,12 @@ __device__ __forceinline__ void play_role(
         u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps
 template <bool RANDOM, bool HIST>
 __device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
-    u32 ep = launch_epoch(epoch), par = ep & 1u;
+    u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
-        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
+        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
     else
-        play_role<RANDOM, HIST>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, par, action_in,
-                                action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
-    launch_done(epoch, ep);
+        play_role<RANDOM, HIST>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
+                                action_in, action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
 }
 #define TK_PLAY_FWD n, seed, offset, mix, flags, cards, stride, play_groups, epoch, fan, action_in, action_out, reward, done, trick, obs, \
                     hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps
@@ -1578,10 +1590,9 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     uint16_t *__restrict__ trick, u64 *__restrict__ obs_out, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
-    u32 ep = launch_epoch(epoch), par = ep & 1u;
+    u32 count = launch_count(epoch);          // (in flight under the policy's first loads)
     if (blockIdx.x >= play_groups) {
-        refill_role(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, par, fan, aux, rlist, rcount);
-        launch_done(epoch, ep);
+        refill_role(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
         return;
     }
     __shared__ uint8_t act_s[2 * PM_M];
@@ -1590,8 +1601,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     __syncthreads();
     u32 tid = threadIdx.x;
     play_role<false, true>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n,
-                           par, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
-    launch_done(epoch, ep);
+                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
 }
 
 #endif  // TK_BLOCK == 256
@@ -1728,8 +1738,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 64 * sizeof(u32));
-    if (r == hipSuccess) r = hipMemset(e->epoch, 0, 64 * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 32 * TK_EPOCH_SHARDS * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
@@ -1818,10 +1828,12 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
                        groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, \
                        e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, e->stamps)
     bool wide = e->wide_regs;                                 // (see k_play_wide)
+
     if (!random) TK_LAUNCH_PLAY(k_play, false, true);
     else if (e->hist) { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, true); else TK_LAUNCH_PLAY(k_play, true, true); }
     else { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, false); else TK_LAUNCH_PLAY(k_play, true, false); }
 #undef TK_LAUNCH_PLAY
+
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,

@@ -6,8 +6,11 @@ bench.py reads for roofline.traffic.
 
 FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch.  On gfx950 FETCH_SIZE counts a wide
 coalesced read stream at half its bytes (MI355X_MICROARCH.md, rocprofv3/HBM section; calibrated
-here on k_legal, which reads 32 B per game): it is doubled; WRITE_SIZE is exact."""
+here on k_legal, which reads 32 B per game): it is doubled; WRITE_SIZE is exact.
+The output carries the hash of the kernel sources it was measured on (bench.kernel_src_sha)."""
 import csv, glob, json, os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 def collect(d, counter):
     per = collections.defaultdict(list)
@@ -20,6 +23,7 @@ def collect(d, counter):
     return per
 
 def main():
+    import bench
     fetch_dir, write_dir, cards, games, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     fe, wr = collect(fetch_dir, "FETCH_SIZE"), collect(write_dir, "WRITE_SIZE")
     kernels = {}
@@ -32,18 +36,31 @@ def main():
             if v:
                 e[cname] = {"launches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
         kernels[name] = e
-    play = [k for k in kernels if "k_play<true>" in k or "k_playILb1" in k]
     res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-                     "--steps 960 --warmup 192 --no-cpu-baseline --no-extras (%d cards per launch, %d games); KB per launch "
-                     "as reported; FETCH_SIZE doubled for bytes (gfx950: a wide coalesced read stream is counted at half)" % (cards, games),
+                     "--steps 20 --warmup 4 --repeats 2 --no-cpu-baseline (%d cards per launch in the headline leg, %d games); KB per "
+                     "launch as reported; FETCH_SIZE doubled for bytes (gfx950: a wide coalesced read stream is counted at half)" % (cards, games),
+           "kernel_src_sha": bench.kernel_src_sha(),
            "kernels": kernels, "games_per_launch": games, "cards_per_launch": cards}
+    def traffic(k):
+        f, w = kernels[k].get("FETCH_SIZE", {}).get("mean_KB"), kernels[k].get("WRITE_SIZE", {}).get("mean_KB")
+        return None if f is None or w is None else int(round((2 * f + w) * 1024))
+    # the multi-card random-policy kernel (k_play / k_play_wide <true, *>): the headline leg dominates its launches
+    play = [k for k in kernels if "k_play" in k and "<true" in k.replace(" ", "")]
     if play:
-        # steady-state launches only: the largest launch count belongs to the timed mode
         k = max(play, key=lambda q: kernels[q].get("FETCH_SIZE", {}).get("launches", 0))
-        f, w = kernels[k]["FETCH_SIZE"]["mean_KB"], kernels[k]["WRITE_SIZE"]["mean_KB"]
-        t = int(round((2 * f + w) * 1024))
-        res["k_play_traffic_bytes_per_launch_cards%d" % cards] = t
-        res["bytes_per_step"] = t / (games * cards)
+        res["k_play_kernel"] = k
+        res["k_play_traffic_bytes_per_launch_cards%d" % cards] = traffic(k)
+        res["bytes_per_step"] = traffic(k) / (games * cards)
+        res["note"] = ("the side legs (one trick / one card per launch) launch the same kernel with fewer cards: the mean over its "
+                       "launches is dominated by, but not purely, the %d-card launches; the headline-only passes are in *_headline*" % cards)
+    # the step API's kernel (k_play<false, true>: one card per launch, external action array)
+    step = [k for k in kernels if "k_play" in k and "<false" in k.replace(" ", "")]
+    if step:
+        res["k_step_kernel"] = step[0]
+        res["k_step_traffic_bytes_per_launch"] = traffic(step[0])
+        pol = [k for k in kernels if k.endswith("k_policy")]
+        if pol:
+            res["k_policy_traffic_bytes_per_launch"] = traffic(pol[0])
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
