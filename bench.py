@@ -3,12 +3,12 @@
 (BASELINE.json metric; workload = configs[2]: mixed Klop/Berac/Navadna contracts,
 uniform-random policy, synthetic deals).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 20          (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One bench "step" = one pass of the hot path over the batch = ONE launch of
-tarok_krog_random: `--cards-per-launch` (default 48 = twelve tricks) lock-steps of every
+tarok_krog_random: `--cards-per-launch` (default 64 = sixteen tricks) lock-steps of every
 one of a rank's 65,536 games.  One lock-step = one card played in each game
 (Tarok.py:48-56): legal mask of the seat to move, a uniform random legal card (the Bot
 policy, Igralec.py:158-159), the card applied, trick resolution and scoring, finished
@@ -67,7 +67,7 @@ def graph_size(passes, limit):
     return best if best >= min(8, limit) else limit
 
 
-def plan_region(passes, cards, graph_lock_steps=1536, launches_per_graph=None):
+def plan_region(passes, cards, graph_lock_steps=2048, launches_per_graph=None):
     """How `passes` launches of `cards` lock-steps each are enqueued (pure; tests/test_bench_plan.py).
     launches_per_graph: use this graph size (a warm-up that must capture the timed region's graph).
 
@@ -165,20 +165,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
                     help="timed passes of the hot path = kernel launches of --cards-per-launch lock-steps each "
-                         "(default 200 x 48 = 9,600 lock-steps, ~260 games per slot)")
+                         "(default 200 x 64 = 12,800 lock-steps, ~350 games per slot)")
     ap.add_argument("--warmup", type=int, default=20, help="untimed passes (raised to one whole graph)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps passes in all, reported as a spread")
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--graph-chunk", type=int, default=1536, help="at most this many lock-steps per replayed hipGraph (0 = eager)")
-    ap.add_argument("--cards-per-launch", type=int, default=48,
+    ap.add_argument("--graph-chunk", type=int, default=2048, help="at most this many lock-steps per replayed hipGraph (0 = eager)")
+    ap.add_argument("--cards-per-launch", type=int, default=64,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
-                         "48 = twelve tricks; 1 = one card per launch)")
+                         "48 = twelve tricks = the longest game; 64 = sixteen tricks, the fastest at 65,536 games; 1 = one card "
+                         "per launch), at most 192")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     ap.add_argument("--strict", action="store_true", help="exit 1 (after printing the line) when a side leg failed")
     args = ap.parse_args()
-    if args.steps < 1 or args.warmup < 0 or not (1 <= args.cards_per_launch <= 48):
-        ap.error("--steps >= 1, --warmup >= 0, 1 <= --cards-per-launch <= 48")
+    if args.steps < 1 or args.warmup < 0 or not (1 <= args.cards_per_launch <= 192):
+        ap.error("--steps >= 1, --warmup >= 0, 1 <= --cards-per-launch <= 192")
 
     import torch
     from tarok_amd import TarokVecEnv, karte as K, sharding

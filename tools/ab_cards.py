@@ -4,6 +4,8 @@ us/step of tarok_run_random for (mix, cards per launch) pairs."""
 import sys, os, subprocess, json, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = [("all", 48), ("klop", 48)]
+if os.environ.get("AB_CASES"):          # e.g. AB_CASES=all:48,all:64
+    CASES = [(c.split(":")[0], int(c.split(":")[1])) for c in os.environ["AB_CASES"].split(",")]
 
 def child(n):
     sys.path.insert(0, os.path.dirname(HERE))
@@ -12,13 +14,13 @@ def child(n):
     out = {}
     for mixname, cards in CASES:
         env = TarokVecEnv(n, seed=0, mix={"all": K.MIX_ALL, "klop": 16, "berac": 23}[mixname])
-        chunk = 192 if 192 % (2 * cards) == 0 else 2 * cards * (96 // cards or 1)
+        chunk = cards * 4
         best = 1e9
         for rep in range(3):
             env.reset()
-            env.run_random(960 // chunk * chunk, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True)
+            env.run_random(max(1, 960 // chunk) * chunk, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True)
             torch.cuda.synchronize()
-            steps = 4800 // chunk * chunk
+            steps = max(1, 9600 // chunk) * chunk
             t0 = time.perf_counter()
             env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True)
             torch.cuda.synchronize()

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tarok_amd import TarokVecEnv, karte as K, _native
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-for cards in (48, 96, 144, 192):
+for cards in (48, 64, 72, 80):
     env = TarokVecEnv(n, seed=0, mix=K.MIX_ALL)
     chunk = cards * 4
     best = 1e9

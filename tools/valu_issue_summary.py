@@ -46,14 +46,18 @@ def isa_mix():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                            "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     L = open(out).read().split("\n")
-    a = next(i for i, l in enumerate(L) if l.startswith("_Z6k_playILb1EE"))
+    a = next(i for i, l in enumerate(L) if l.startswith("_Z6k_playILb1ELb0EE"))      # k_play<true, false>: the 128-VGPR build
     b = next(i for i in range(a, len(L)) if L[i].startswith(".Lfunc_end"))
     K = L[a:b]
     heads = [i for i, l in enumerate(K) if "Loop Header: Depth=1" in l and "Inner" not in l]
-    # the play role's three card loops follow the refill loop; the trick-aligned one is the last
-    h = heads[-1]
-    name = re.match(r"\.(LBB\d+_\d+):", K[h]).group(1)[1:]
-    e = next(i for i in range(h + 1, len(K)) if K[i].startswith(".LBB") and ("Header=" + name) not in K[i] and ("Parent Loop " + name) not in K[i])
+
+    def extent(h):
+        name = re.match(r"\.(LBB\d+_\d+):", K[h]).group(1)[1:]
+        return next(i for i in range(h + 1, len(K)) if K[i].startswith(".LBB") and ("Header=" + name) not in K[i] and ("Parent Loop " + name) not in K[i])
+    # the play role's card loops follow the refill loop; the two trick-aligned ones are the last two, and the one
+    # a rollout runs in (action and done rows given, no trick row) is the one with fewer stores
+    cand = [(h, extent(h)) for h in heads[-2:]]
+    h, e = min(cand, key=lambda he: sum(1 for l in K[he[0]:he[1]] if l.strip().startswith("global_store")))
     mix = collections.Counter()
     other = collections.Counter()
     for l in K[h:e]:
