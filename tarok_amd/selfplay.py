@@ -250,7 +250,7 @@ class SelfPlay:
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(s):
-                self._collect_body(2)                 # an even number of env launches (refill-list parity)
+                self._collect_body(2)                 # (any number: the refill-list parity lives on the device)
             torch.cuda.current_stream(self.device).wait_stream(s)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
