@@ -182,11 +182,12 @@ class TarokVecEnv:
             _native.check(self.L.tarok_policy_random(self._h, self._p(words), self._p(self.action), self._stream()))
         return self.action
 
-    def step_random(self, auto_reset=False, tricks=False):
+    def step_random(self, auto_reset=False, tricks=False, reward_ref=False):
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_step_random(self._h, self._p(self.action), self._p(self.reward), self._p(self.done),
                                                    self._p(self._trick_buf(tricks)), self._p(self.obs_words),
-                                                   K.AUTO_RESET if auto_reset else 0, self._stream()))
+                                                   (K.AUTO_RESET if auto_reset else 0) | (K.REWARD_REF if reward_ref else 0),
+                                                   self._stream()))
         return Obs(self.obs_words), self.reward, self.done
 
     def prefetch(self):
@@ -206,7 +207,7 @@ class TarokVecEnv:
             self._kb_cards = cards
         return self._kb
 
-    def krog_random(self, cards=4, auto_reset=False):
+    def krog_random(self, cards=4, auto_reset=False, reward_ref=False):
         """`cards` cards of every game in one launch, Bot policy in-kernel (cards=4: one trick =
         one pass of the reference's krog).  Returns dict of [cards,N] tensors: action, reward
         [cards,N,4] (valid where done), done, trick, obs (observation words); also updates
@@ -215,7 +216,8 @@ class TarokVecEnv:
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_krog_random(self._h, int(cards), self.n, self._p(kb["action"]), self._p(kb["reward"]),
                                                    self._p(kb["done"]), self._p(kb["trick"]), self._p(kb["obs"]),
-                                                   K.AUTO_RESET if auto_reset else 0, self._stream()))
+                                                   (K.AUTO_RESET if auto_reset else 0) | (K.REWARD_REF if reward_ref else 0),
+                                                   self._stream()))
             self.obs_words.copy_(kb["obs"][cards - 1])
         return kb
 

@@ -193,6 +193,34 @@ def test_reward_ref_is_what_rezultat_igre_folds_in(T, E, traces):
     env.close()
 
 
+def test_reward_ref_in_multi_card_launches_equals_the_one_card_path(T):
+    """TAROK_REWARD_REF through the deferred scoring of tarok_krog_random (finished games are scored later, on
+    dense lanes) against tarok_step_random's on-the-spot path: same reward rows, same done rows, same score sums,
+    on an all-Berac batch (several finishes per slot and launch, ring drains inside the loop) and a mixed one."""
+    import torch
+    for mix, n in ((T.karte.MIX_FIXED + 7, 5000), (T.karte.MIX_FIXED + 9, 3000), (T.karte.MIX_ALL, 20000)):
+        a = T.TarokVecEnv(n, seed=8, mix=mix)
+        b = T.TarokVecEnv(n, seed=8, mix=mix)
+        a.reset(episode=0)
+        b.reset(episode=0)
+        for cards in (48, 64, 20):
+            kb = a.krog_random(cards, auto_reset=True, reward_ref=True)
+            for c in range(cards):
+                _, rw, dn = b.step_random(auto_reset=True, reward_ref=True)
+                d = dn.bool()
+                assert torch.equal(kb["done"][c], dn), (mix, cards, c)
+                assert torch.equal(kb["reward"][c][d], rw[d]), (mix, cards, c)
+        ea, sa = a.counters()
+        eb, sb = b.counters()
+        assert (ea == eb).all() and (sa == sb).all()
+        if mix != T.karte.MIX_ALL:                                       # a Berac's defenders never see their 0
+            fin = kb["done"].bool()
+            vals = kb["reward"][fin].unique().tolist()
+            assert set(vals) <= {-90, -70, 70, 90, -20, 20} and 0 not in vals
+        a.close()
+        b.close()
+
+
 def test_observe_ref_at_65536_games_round_trips_its_own_fields(T):
     """Full size: the record of every game is consistent with the env's other outputs (legal mask = the
     observation word's, T's rule, one-hot rows, own-row count) — size-independent properties."""
