@@ -7,8 +7,8 @@
 //     X0 = C plane [53:0] | n_in_trick<<54 (2) | leader<<56 (2) | trick_no<<58 (4) | phase<<62 (2)
 //     X1 = talon 6x6-bit ids [35:0] | current trick 4x6-bit ids [59:36] | tl<<60 (3) | error<<63
 //   seat pair (rewritten only when a trick is resolved: every 4th card)
-//     Y0 = A plane [53:0] | contract<<54 (4) | declarer<<58 (2) | king<<60 (2)
-//     Y1 = B plane [53:0] | team<<54 (4) | epar<<58 (3) | cprev<<61 (3)
+//     Y0 = A plane [53:0] | contract<<54 (4) | declarer<<58 (2) | king<<60 (2) | cprev[3:2]<<62
+//     Y1 = B plane [53:0] | team<<54 (4) | epar<<58 (4) | cprev[1:0]<<62
 //          epar = the slot's episode number mod TK_AHEAD: says which of the slot's next-game
 //          lines holds the next game; cprev = how many of them (the farthest ahead) were put
 //          on a refill list by the previous launch, i.e. are being re-dealt during this one
@@ -60,7 +60,7 @@ __device__ __forceinline__ void unpack(Game &g, u64 x0, u64 x1, u64 y0, u64 y1) 
     g.trick = (u32)(x1 >> 36) & 0xFFFFFF;
     g.tl = (u32)(x1 >> 60) & 7; g.error = (u32)(x1 >> 63);
     g.contract = m2 & 15; g.declarer = (m2 >> 4) & 3; g.king = (m2 >> 6) & 3;
-    g.team = m3 & 15; g.epar = (m3 >> 4) & 7; g.cprev = (m3 >> 7) & 7;
+    g.team = m3 & 15; g.epar = (m3 >> 4) & 15; g.cprev = (m3 >> 8) | ((m2 >> 8) << 2);
 }
 
 __device__ __forceinline__ void pack_play(const Game &g, u64 &x0, u64 &x1) {
@@ -68,8 +68,8 @@ __device__ __forceinline__ void pack_play(const Game &g, u64 &x0, u64 &x1) {
     x1 = g.talon | ((u64)g.trick << 36) | ((u64)g.tl << 60) | ((u64)g.error << 63);
 }
 __device__ __forceinline__ void pack_seats(const Game &g, u64 &y0, u64 &y1) {
-    y0 = g.A | ((u64)(g.contract | (g.declarer << 4) | (g.king << 6)) << 54);
-    y1 = g.B | ((u64)(g.team | (g.epar << 4) | (g.cprev << 7)) << 54);
+    y0 = g.A | ((u64)(g.contract | (g.declarer << 4) | (g.king << 6) | ((g.cprev >> 2) << 8)) << 54);
+    y1 = g.B | ((u64)(g.team | (g.epar << 4) | ((g.cprev & 3) << 8)) << 54);
 }
 __device__ __forceinline__ void pack(const Game &g, u64 &x0, u64 &x1, u64 &y0, u64 &y1) {
     pack_play(g, x0, x1);

@@ -40,7 +40,7 @@
 #define TK_RC(group, par) ((((size_t)(group)) * 2 + (par)) * 32)
 
 #ifndef TK_AHEAD
-#define TK_AHEAD 7                  // next-game lines per slot (<= 7: epar and cprev are 3 bits each)
+#define TK_AHEAD 14                 // next-game lines per slot (<= 15: epar and cprev are 4 bits each)
 #endif
 #define TK_LINE(episode) ((u32)(episode) % (u32)TK_AHEAD)
 #define TK_FINQ 128                 // entries of a play wave's finished-games ring (a power of two >= 128)
@@ -54,7 +54,7 @@
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
 
-// Per-slot side record: TK_AHEAD (seven) 64-byte next-game lines.  Line b holds the dealt-ahead
+// Per-slot side record: TK_AHEAD (fourteen) 64-byte next-game lines.  Line b holds the dealt-ahead
 // game whose episode number is b mod TK_AHEAD: its packed pairs, its RNG key and the episode number
 // it is (the validity tag).  A 64-byte AuxLine is HALF an L2 line (128 B on MI355X), and a slot's
 // 448-byte record shares its first / last L2 line with a neighbouring slot.  That is safe because
@@ -71,7 +71,7 @@ struct __attribute__((aligned(64))) AuxLine {
 struct __attribute__((aligned(64))) Aux { AuxLine line[TK_AHEAD]; };
 static_assert(sizeof(AuxLine) == 64 && sizeof(Aux) == 64 * TK_AHEAD, "64 bytes per next-game line");
 static_assert((TK_BLOCK * sizeof(Aux)) % 128 == 0, "a play group's next-game lines end on an L2 line boundary");
-static_assert(TK_AHEAD >= 2 && TK_AHEAD <= 7, "epar / cprev are 3-bit fields");
+static_assert(TK_AHEAD >= 2 && TK_AHEAD <= 15, "epar / cprev are 4-bit fields");
 // What a finishing game always touches: the slot's episode number and its summed scores.  Kept
 // apart from the next-game lines: those are written by refill workgroups, these by the slot's own
 // play workgroup, which runs on another XCD (another, non-coherent L2) — the two must not share
@@ -91,7 +91,7 @@ struct tarok_env {
     ulonglong2 *s01, *s23;   // packed state
     Aux *aux;                // next-game lines per slot
     Counters *cnt;           // episode number and score sums per slot
-    uint8_t *nstale;         // bit k: the game k+1 ahead is missing and not on any refill list
+    uint16_t *nstale;        // bit k: the game k+1 ahead is missing and not on any refill list
                              // (after tarok_reset; what k_prefetch scans); padded to 1024 slots
     u64 *gkey;               // RNG key of the slot's current game
     uint8_t *hist;           // [48][n] play history (card p of the slot's current game), TAROK_HISTORY envs only
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
     const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    uint8_t *__restrict__ nstale, u64 *__restrict__ gkey) {
+    uint16_t *__restrict__ nstale, u64 *__restrict__ gkey) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 key = game_key(seed, offset + (u64)i, episode);
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
     bool bad = false;
 #pragma unroll
     for (int b = 0; b < TK_AHEAD; b++) aux[i].line[b].nep = 0xFFFFFFFFu;   // all next-game lines: empty
-    nstale[i] = (1u << TK_AHEAD) - 1;
+    nstale[i] = (uint16_t)((1u << TK_AHEAD) - 1);
     if (deals) {
         const uint8_t *p = deals + i * 54;
         u64 h[4] = {0, 0, 0, 0};
@@ -216,24 +216,25 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
 // so the sorting network runs on dense lanes.
 __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
                                                       Aux *__restrict__ aux, const Counters *__restrict__ cnt,
-                                                      uint8_t *__restrict__ nstale) {
+                                                      uint16_t *__restrict__ nstale) {
     __shared__ unsigned short list[TK_AHEAD * TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
     if (threadIdx.x == 0) count = 0;
     __syncthreads();
-    u32 f = reinterpret_cast<const u32 *>(nstale + base)[threadIdx.x];   // 4 slots; array is padded
+    const u64 ALL = (1u << TK_AHEAD) - 1;
+    u64 f = reinterpret_cast<const u64 *>(nstale + base)[threadIdx.x];   // 4 slots x 16 flag bits; the array is padded
     if (f) {
-        u32 c = __popc(f & (0x01010101u * ((1u << TK_AHEAD) - 1)));
+        u32 c = (u32)__popcll(f & (0x0001000100010001ULL * ALL));
         u32 pos = atomicAdd(&count, c);
 #pragma unroll
         for (u32 k = 0; k < 4; k++) {
-            u32 fk = (f >> (8 * k)) & ((1u << TK_AHEAD) - 1);
+            u32 fk = (u32)(f >> (16 * k)) & (u32)ALL;
 #pragma unroll
             for (u32 b = 0; b < TK_AHEAD; b++)
                 if (fk & (1u << b)) list[pos++] = (unsigned short)((threadIdx.x * 4 + k) * TK_AHEAD + b);
         }
-        reinterpret_cast<u32 *>(nstale + base)[threadIdx.x] = 0;
+        reinterpret_cast<u64 *>(nstale + base)[threadIdx.x] = 0;
     }
     __syncthreads();
     u32 total = count;
@@ -378,7 +379,8 @@ __device__ __forceinline__ void play_role(
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
-    __shared__ u64 push_list[TK_REFILL_CAP];
+    __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
+    __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
     __shared__ u32 push_count;
     // Deferred scoring (the multi-card kernel): a game that ends leaves its final state in a per-wave LDS ring
     // (9 dwords) instead of being scored on the spot — with ~10 % of the slots finishing per trick the
@@ -558,11 +560,17 @@ __device__ __forceinline__ void play_role(
                 ev_renew++;
                 if (__ballot(renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed)) ev_lazy++;
 #endif
-                if (renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed) {
-                    // third game of a launch (or second, when one line was loaded): fetch it now
-                    const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
-                    na = ln->n01; nb = ln->n23; nkey = ln->nkey;
-                    ok1 = ln->nep == cur_ep + 1;
+                // A third or later game of a launch (the two preloaded lines are used up) is fetched on the spot:
+                // a memory round trip (~550 cycles) that nothing hides.  So when one lane has to, EVERY lane that
+                // has used its preloaded lines up takes its next game's line along — finishing or not: the one
+                // wait serves them all, and most lanes hold their line by the time they finish.
+                bool lacks = spec && !blocked && !ok1 && consumed >= 1 && consumed < allowed;
+                if (__ballot(renew && lacks)) {
+                    if (lacks) {
+                        const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
+                        na = ln->n01; nb = ln->n23; nkey = ln->nkey;
+                        ok1 = ln->nep == cur_ep + 1;
+                    }
                     TK_WAIT_LOADS();
                 }
                 bool swap = renew && !blocked && ok1;
@@ -669,13 +677,17 @@ __device__ __forceinline__ void play_role(
     if (stamps) t_play = __builtin_amdgcn_s_memtime() - t_cyc0;
     if (valid && np) {
         u32 pos = atomicAdd(&push_count, np);
-        for (u32 j = 0; j < np; j++) push_list[pos + j] = ((u64)(cur_ep + TK_AHEAD - j) << 32) | tid;
+        push_ep[tid] = cur_ep;
+        for (u32 j = 0; j < np; j++) push_list[pos + j] = (unsigned short)(j * TK_BLOCK + tid);
     }
     __syncthreads();
     u32 total = push_count;
     u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
     if (active)
-        for (u32 j = tid; j < total; j += TK_BLOCK) lst[j] = push_list[j];
+        for (u32 j = tid; j < total; j += TK_BLOCK) {              // list entry: episode to deal << 32 | slot in group
+            u32 en = push_list[j], t = en % TK_BLOCK;
+            lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
+        }
     if (tid == 0) rcount[TK_RC(group, par)] = total;
     if (stamps && active && (tid & 63) == 0) {     // diagnostics only
         u64 w = (u64)i >> 6;
@@ -1663,7 +1675,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     u32 talon_left = (u32)(m >> 46) & 7, choice = (u32)(m >> 49) & 7;
     g.phase = (u32)(m >> 52) & 3; g.error = (u32)(m >> 54) & 1;
     g.epar = TK_LINE(cnt[i].episode);
-    g.cprev = (u32)(s23[i].y >> 61) & 7;            // lines on a refill list stay off limits for the next launch
+    {   // lines on a refill list stay off limits for the next launch
+        ulonglong2 old = s23[i];
+        g.cprev = ((u32)(old.y >> 62) & 3u) | (((u32)(old.x >> 62) & 3u) << 2);
+    }
     g.talon = in[8 * n + i] & ((1ULL << 36) - 1);
     g.tl = g.contract == TK_KLOP ? talon_left : ((has_exchange(g.contract) || g.contract == TK_SOLO_BREZ) ? choice : 0);
     u64 seatc[4];
@@ -1726,7 +1741,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->wide_regs = n_games <= 2 * 1024 * 64;                  // 1,024 SIMDs x 64 lanes x 2 waves
     if (const char *f = getenv("TAROK_WIDE_REGS")) e->wide_regs = atoi(f) != 0;      // diagnostics (A/B runs)
     if (const char *f = getenv("TAROK_REFILL_FAN")) { int v = atoi(f); if (v >= 1 && v <= TK_REFILL_FAN) e->refill_fan = (uint32_t)v; }
-    size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS;
+    size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->aux, (size_t)n_games * sizeof(Aux));

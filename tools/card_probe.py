@@ -18,7 +18,7 @@ cards = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 for mixname, mix in (("all", K.MIX_ALL), ("klop", 16)):
     env = TarokVecEnv(n, seed=0, mix=mix)
     env.reset()
-    env.run_random(960, cards_per_launch=cards, graph_chunk=192, auto_reset=True)
+    env.run_random(cards * 8, cards_per_launch=cards, graph_chunk=cards * 4, auto_reset=True)
     nw = n // 64
     st = torch.zeros((nw, 3), dtype=torch.int64, device="cuda")
     _native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))

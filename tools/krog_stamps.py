@@ -8,7 +8,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cards = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 env = TarokVecEnv(n, seed=0, mix=K.MIX_ALL)
 env.reset()
-env.run_random(960, cards_per_launch=cards, graph_chunk=192, auto_reset=True, prefetch_every=0)
+env.run_random(cards * 8, cards_per_launch=cards, graph_chunk=cards * 4, auto_reset=True)
 nw = (n + 63) // 64
 st = torch.zeros((nw, 3), dtype=torch.int64, device="cuda")
 _native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
