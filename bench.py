@@ -3,12 +3,12 @@
 (BASELINE.json metric; workload = configs[2]: mixed Klop/Berac/Navadna contracts,
 uniform-random policy, synthetic deals).
 
-    python bench.py --gpus 1 --steps 200 --warmup 20          (the defaults)
+    python bench.py --gpus 1 --steps 100 --warmup 10          (the defaults)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One bench "step" = one pass of the hot path over the batch = ONE launch of
-tarok_krog_random: `--cards-per-launch` (default 64 = sixteen tricks) lock-steps of every
+tarok_krog_random: `--cards-per-launch` (default 128 = thirty-two tricks) lock-steps of every
 one of a rank's 65,536 games.  One lock-step = one card played in each game
 (Tarok.py:48-56): legal mask of the seat to move, a uniform random legal card (the Bot
 policy, Igralec.py:158-159), the card applied, trick resolution and scoring, finished
@@ -55,7 +55,7 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_STEP = 54
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PROFILE_TAG = "r02"             # profiles/<tag>_* are the files read below
-SIDE_LOCK_STEPS_CAP = 9600      # side legs: at most this many lock-steps per timed region
+SIDE_LOCK_STEPS_CAP = 7680      # side legs: at most this many lock-steps per timed region
 
 
 def graph_size(passes, limit):
@@ -67,7 +67,7 @@ def graph_size(passes, limit):
     return best if best >= min(8, limit) else limit
 
 
-def plan_region(passes, cards, graph_lock_steps=2048, launches_per_graph=None):
+def plan_region(passes, cards, graph_lock_steps=4096, launches_per_graph=None):
     """How `passes` launches of `cards` lock-steps each are enqueued (pure; tests/test_bench_plan.py).
     launches_per_graph: use this graph size (a warm-up that must capture the timed region's graph).
 
@@ -163,17 +163,17 @@ def cpu_baseline(n_games_chunk, mix, min_seconds=10.0, max_seconds=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200,
+    ap.add_argument("--steps", type=int, default=100,
                     help="timed passes of the hot path = kernel launches of --cards-per-launch lock-steps each "
-                         "(default 200 x 64 = 12,800 lock-steps, ~350 games per slot)")
-    ap.add_argument("--warmup", type=int, default=20, help="untimed passes (raised to one whole graph)")
+                         "(default 100 x 128 = 12,800 lock-steps, ~350 games per slot)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed passes (raised to one whole graph)")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps passes in all, reported as a spread")
     ap.add_argument("--games", type=int, default=65536, help="games per GPU")
-    ap.add_argument("--graph-chunk", type=int, default=2048, help="at most this many lock-steps per replayed hipGraph (0 = eager)")
-    ap.add_argument("--cards-per-launch", type=int, default=64,
+    ap.add_argument("--graph-chunk", type=int, default=4096, help="at most this many lock-steps per replayed hipGraph (0 = eager)")
+    ap.add_argument("--cards-per-launch", type=int, default=128,
                     help="headline mode: cards of every game per launch (4 = one trick = one pass of the reference's krog; "
-                         "48 = twelve tricks = the longest game; 64 = sixteen tricks, the fastest at 65,536 games; 1 = one card "
-                         "per launch), at most 192")
+                         "48 = twelve tricks = the longest game; 128 = thirty-two tricks, where the time between launches "
+                         "stops mattering at 65,536 games; 1 = one card per launch), at most 192")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements")
     ap.add_argument("--strict", action="store_true", help="exit 1 (after printing the line) when a side leg failed")
@@ -222,9 +222,10 @@ def main():
 
     def leg(cards, passes):
         """A side leg: reset, warm up (graph capture untimed), one timed region.  -> (plan, seconds)"""
-        plan = plan_region(passes, cards, args.graph_chunk)
+        chunk = min(args.graph_chunk, 1536)          # (graphs of at most 1,536 small launches)
+        plan = plan_region(passes, cards, chunk)
         env.reset(episode=0)
-        run(plan_region(min(passes, 2 * plan["launches_per_graph"]), cards, args.graph_chunk, plan["launches_per_graph"]))
+        run(plan_region(min(passes, 2 * plan["launches_per_graph"]), cards, chunk, plan["launches_per_graph"]))
         return plan, timed(plan)
 
     # ---- headline: --steps launches of tarok_krog_random(cards); per card: legal mask -> uniform random

@@ -564,12 +564,19 @@ __device__ __forceinline__ void play_role(
                 // a memory round trip (~550 cycles) that nothing hides.  So when one lane has to, EVERY lane that
                 // has used its preloaded lines up takes its next game's line along — finishing or not: the one
                 // wait serves them all, and most lanes hold their line by the time they finish.
+                // (and the line after it, into the second buffer)
                 bool lacks = spec && !blocked && !ok1 && consumed >= 1 && consumed < allowed;
                 if (__ballot(renew && lacks)) {
+                    bool lacks2 = spec && !blocked && !ok2 && consumed >= 1 && consumed + 1 < allowed;
                     if (lacks) {
                         const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
                         na = ln->n01; nb = ln->n23; nkey = ln->nkey;
                         ok1 = ln->nep == cur_ep + 1;
+                    }
+                    if (lacks2) {
+                        const AuxLine *l2 = &aux[i].line[TK_LINE(cur_ep + 2)];
+                        na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
+                        ok2 = l2->nep == cur_ep + 2;
                     }
                     TK_WAIT_LOADS();
                 }

@@ -14,7 +14,7 @@ import torch
 import bench
 
 STEPS = [1, 3, 4, 20, 47, 48, 95, 96, 200, 9600]
-CARDS = [0, 1, 4, 5, 48, 64]
+CARDS = [0, 1, 4, 5, 48, 64, 128]
 
 
 def run_random_model(n_steps, cards, graph_chunk):
@@ -34,7 +34,7 @@ def run_random_model(n_steps, cards, graph_chunk):
 @pytest.mark.parametrize("cards", CARDS)
 @pytest.mark.parametrize("steps", STEPS)
 def test_plan_never_times_zero_launches_and_matches_the_library(steps, cards):
-    p = bench.plan_region(steps, cards, 2048)
+    p = bench.plan_region(steps, cards, 4096)
     unit = max(1, cards)
     assert p["launches"] == steps >= 1                       # exactly the requested passes are timed
     assert p["lock_steps"] == steps * unit
@@ -49,7 +49,7 @@ def test_plan_never_times_zero_launches_and_matches_the_library(steps, cards):
         assert "%d eager launch(es)" % p["eager_launches"] in text
     # a warm-up that captures the timed region's graph: same graph size, at least one whole graph
     for warm in (0, 1, 5, 960):
-        w = bench.plan_region(warm, cards, 2048, p["launches_per_graph"])
+        w = bench.plan_region(warm, cards, 4096, p["launches_per_graph"])
         assert w["graph_chunk"] == p["graph_chunk"] and w["graph_replays"] >= 1 and w["launches"] >= max(warm, 1)
         assert run_random_model(w["lock_steps"], cards, w["graph_chunk"]) == (w["graph_replays"], w["eager_launches"])
 
@@ -128,7 +128,7 @@ def test_bench_line_on_a_fake_env(fake_gpu, monkeypatch, capsys, argv):
     out = capsys.readouterr()
     line = json.loads(out.out.strip().splitlines()[-1])
     a = dict(zip(argv[::2], argv[1::2]))
-    steps, cards = int(a.get("--steps", 200)), int(a.get("--cards-per-launch", 64))
+    steps, cards = int(a.get("--steps", 100)), int(a.get("--cards-per-launch", 128))
     assert line["steps"] == line["steps_requested"] == steps and line["warmup"] >= line["warmup_requested"]
     assert line["value"] > 0 and line["ms_per_step"] > 0 and line["dtype"] == "u64" and line["n_gpus"] == 1
     assert line["lock_steps_timed"] == steps * cards

@@ -3,7 +3,7 @@
 # usage: bash tools/profile_round.sh <tag>      (writes gpurun_out/<tag>/; copy the summaries into profiles/)
 set -o pipefail
 TAG=${1:-r02}
-CARDS=${2:-64}          # the bench's default cards per launch
+CARDS=${2:-128}          # the bench's default cards per launch
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
