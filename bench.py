@@ -18,7 +18,8 @@ resident in HBM between launches; every per-card output (action, observation wor
 scores) is written to HBM.
     value = games x cards per launch x steps x ranks / max-over-ranks time   [env steps/s]
 Exactly --steps launches are timed (never fewer than one; --warmup is raised to one whole
-graph so that the capture is untimed: `warmup` reports what ran).  Weak scaling: each rank
+graph, so that the capture is untimed, and to ~25 ms of launches, so that the GPU has left its
+idle clocks: `warmup` reports what ran).  Weak scaling: each rank
 owns its own 65,536 games (global game indices rank*65536...), no collective in the env path.
 
 Extra objects on the JSON line:
@@ -56,6 +57,7 @@ ALGO_BYTES_PER_STEP = 54
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PROFILE_TAG = "r02"             # profiles/<tag>_* are the files read below
 SIDE_LOCK_STEPS_CAP = 7680      # side legs: at most this many lock-steps per timed region
+MIN_WARMUP_LOCK_STEPS = 49152   # the headline's untimed warm-up lasts at least this long (see main)
 
 
 def graph_size(passes, limit):
@@ -232,7 +234,11 @@ def main():
     # legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap -> next observation
     cards = args.cards_per_launch
     plan = plan_region(args.steps, cards, args.graph_chunk)
-    wplan = plan_region(args.warmup, cards, args.graph_chunk, plan["launches_per_graph"])
+    # the untimed warm-up is never shorter than MIN_WARMUP_LOCK_STEPS lock-steps (~25 ms): a fresh process finds the
+    # GPU at idle clocks, and a timed region right after a 1 ms warm-up reads 6 % low (measured: 138.7 G after 20
+    # launches, 147.0 G after 400, same box, same 20 timed launches)
+    wplan = plan_region(max(args.warmup, -(-MIN_WARMUP_LOCK_STEPS // max(1, cards))), cards, args.graph_chunk,
+                        plan["launches_per_graph"])
     env.reset(episode=0)
     run(wplan)                                # the graph is captured here, untimed
     stream = torch.cuda.current_stream(dev)

@@ -144,7 +144,7 @@ def test_bench_line_on_a_fake_env(fake_gpu, monkeypatch, capsys, argv):
     env = FakeEnv.instances[0]
     p = cfg["launch_plan"]
     runs = [c for c in env.calls if c[0] == "run"]
-    assert runs[0][2] == cards and runs[0][3] == p["graph_chunk"] and runs[0][1] >= p["graph_chunk"]     # warm-up
+    assert runs[0][2] == cards and runs[0][3] == p["graph_chunk"] and runs[0][1] >= max(p["graph_chunk"], bench.MIN_WARMUP_LOCK_STEPS)   # warm-up
     assert runs[1:6] == [("run", p["lock_steps"], cards, p["graph_chunk"])] * 5
     # the failing self-play leg is visible: error field, side_leg_errors, stderr — and the line is still there
     assert "error" in line["selfplay_ppo"] and line["side_leg_errors"] and "FAILED" in out.err
