@@ -144,11 +144,11 @@ int tarok_step(tarok_env *env, const uint8_t *action, int16_t *reward_out, uint8
                uint16_t *trick_out, uint64_t *obs_out, int flags, void *stream);
 
 /* Fill, synchronously, every next-game line that tarok_reset emptied (each slot keeps its next
- * SEVEN games dealt ahead: episode+1 .. episode+7, synthetic contract, Bot exchange).  tarok_reset
+ * FOURTEEN games dealt ahead: episode+1 .. episode+14, synthetic contract, Bot exchange).  tarok_reset
  * calls it; afterwards the step kernels keep the lines full themselves — a launch that swaps a
  * finished game's successor in puts the replacement deal on a list that extra workgroups of the
  * NEXT step launch work off while that launch plays — so callers normally never need this.  A
- * slot that finds its line missing anyway (more than seven games finished within two consecutive
+ * slot that finds its line missing anyway (more than fourteen games finished within two consecutive
  * launches) deals the game inside the step kernel (same result). */
 int tarok_prefetch(tarok_env *env, void *stream);
 

@@ -7,13 +7,15 @@
 // HBM bandwidth (no MFMA).
 //
 // Finished games are replaced at once (auto-reset) without a deal on the step's critical path:
-// every slot keeps its next SEVEN games ready in the lines of its Aux record (episode e lives in
-// line e mod 7).  A launch that consumes episode k pushes "deal k+7 into line k mod 7" onto its
+// every slot keeps its next FOURTEEN games ready in the lines of its Aux record (episode e lives in
+// line e mod 14).  A launch that consumes episode k pushes "deal k+14 into line k mod 14" onto its
 // workgroup's refill list; the NEXT launch carries extra workgroups that work those lists off
 // (sorting-network deals on dense lanes) while its own play workgroups run — the ~5 us of deal
-// latency overlaps the next launch instead of following this one.  Seven games ahead let a launch
-// play up to twelve tricks (the shortest game, a Berac lost on trick 1, is 4 cards) practically
-// without ever waiting for a deal.  Lists are double-buffered by launch parity — kept in DEVICE memory
+// latency overlaps the next launch instead of following this one.  The shortest game, a Berac lost on
+// trick 1, is 4 cards: with fourteen lines launches of 128 cards (32 tricks; a slot starts ~3.5 games
+// in one) practically never wait for a deal (with seven, round 1, 64 cards were the limit: a slot that
+// finishes more games within two launches than it has lines deals in place, and the launch is its
+// slowest wave).  Lists are double-buffered by launch parity — kept in DEVICE memory
 // as a count of started workgroups that every step launch advances by its grid size (launch_count /
 // launch_counted), so eager launches and replays of captured graphs (the library's own or a caller's,
 // e.g. torch.cuda.graph) mix freely and in any number.  A line is valid iff its episode tag matches
