@@ -243,6 +243,8 @@ def main():
     run(wplan)                                # the graph is captured here, untimed
     stream = torch.cuda.current_stream(dev)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), stream)
+    ev[0].record(stream)                      # (torch creates the HIP events on their first record: not inside the timed region)
+    ev[1].record(stream)
     dt = timed(plan, ev)
     ev_ms = ev[0].elapsed_time(ev[1])
     env_steps = n * plan["lock_steps"] * world_size
