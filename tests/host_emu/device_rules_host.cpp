@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
         int8_t seats[48];
         uint8_t actions[48];
         int16_t played = 0;
+        Game d = g;                      // the same game through the deferred-scoring form the multi-card kernel uses
         for (int t = 0; t < 48; t++) {
             bool live = g.phase == TK_PHASE_PLAY;
             masks[t] = 0; seats[t] = -1; actions[t] = 255;
@@ -77,19 +78,27 @@ int main(int argc, char **argv) {
                 seats[t] = (int8_t)((g.leader + g.nt) & 3);
                 u32 a = policy_action(key, (u32)t, m);
                 actions[t] = (uint8_t)a;
-                u32 ti;
-                apply_step<true>(g, a, scores, ti);
+                u32 ti, ti2 = 0;
+                u64 untouched = 0x1234;
+                int r1 = apply_step<true>(g, a, scores, ti);
+                int r2 = apply_step<true, true>(d, a, untouched, ti2, false);
+                if (r1 != r2 || untouched != 0x1234 || ti2 != 0 || d.phase != g.phase || (r1 == 1 && final_scores(d) != scores)) {
+                    fprintf(stderr, "deferred scoring differs at game %ld card %d\n", i, t);
+                    return 5;
+                }
                 played++;
             }
         }
-        // pack / unpack round trip of the final state must be lossless
+        // pack / unpack round trip of the final state must be lossless (the line bookkeeping fields included)
+        g.epar = (u32)(i % 14); g.cprev = (u32)(i % 15);
         u64 x0, x1, y0, y1;
         pack(g, x0, x1, y0, y1);
         Game r;
         unpack(r, x0, x1, y0, y1);
         if (r.A != g.A || r.B != g.B || r.C != g.C || r.talon != g.talon || r.trick != g.trick || r.nt != g.nt ||
             r.leader != g.leader || r.trick_no != g.trick_no || r.phase != g.phase || r.contract != g.contract ||
-            r.declarer != g.declarer || r.king != g.king || r.team != g.team || r.tl != g.tl || r.error != g.error) {
+            r.declarer != g.declarer || r.king != g.king || r.team != g.team || r.tl != g.tl || r.error != g.error ||
+            r.epar != g.epar || r.cprev != g.cprev) {
             fprintf(stderr, "pack/unpack mismatch at game %ld\n", i);
             return 4;
         }
