@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
         int8_t seats[48];
         uint8_t actions[48];
         int16_t played = 0;
-        Game d = g;                      // the same game through the deferred-scoring form the multi-card kernel uses
+        Game gd = g;                     // the same game through the deferred-scoring form the multi-card kernel uses
         for (int t = 0; t < 48; t++) {
             bool live = g.phase == TK_PHASE_PLAY;
             masks[t] = 0; seats[t] = -1; actions[t] = 255;
@@ -81,8 +81,8 @@ int main(int argc, char **argv) {
                 u32 ti, ti2 = 0;
                 u64 untouched = 0x1234;
                 int r1 = apply_step<true>(g, a, scores, ti);
-                int r2 = apply_step<true, true>(d, a, untouched, ti2, false);
-                if (r1 != r2 || untouched != 0x1234 || ti2 != 0 || d.phase != g.phase || (r1 == 1 && final_scores(d) != scores)) {
+                int r2 = apply_step<true, true>(gd, a, untouched, ti2, false);
+                if (r1 != r2 || untouched != 0x1234 || ti2 != 0 || gd.phase != g.phase || (r1 == 1 && final_scores(gd) != scores)) {
                     fprintf(stderr, "deferred scoring differs at game %ld card %d\n", i, t);
                     return 5;
                 }
