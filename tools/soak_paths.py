@@ -8,11 +8,17 @@ import numpy as np, torch
 from tarok_amd import TarokVecEnv, karte as K
 from oracle import oracle as O
 n, steps = 65536, 9600
-ref = O.run_autoreset(3, 17, n, K.MIX_ALL, steps)
-for cards, chunk in ((0, 192), (1, 192), (4, 192), (5, 0)):
+from concurrent.futures import ThreadPoolExecutor
+parts = 64
+with ThreadPoolExecutor(16) as ex:
+    res = list(ex.map(lambda k: O.run_autoreset(3, 17 + k * (n // parts), n // parts, K.MIX_ALL, steps), range(parts)))
+ref = {"episode": np.concatenate([r["episode"] for r in res]), "score_sum": np.concatenate([r["score_sum"] for r in res]),
+       "lanes": np.concatenate([r["lanes"] for r in res], axis=1), "obs": np.concatenate([r["obs"] for r in res])}
+print("oracle done", flush=True)
+for cards, chunk in ((0, 192), (1, 192), (4, 192), (5, 0), (48, 192), (64, 640), (160, 1600)):
     env = TarokVecEnv(n, seed=3, mix=K.MIX_ALL, game_offset=17)
     env.reset()
-    st = steps if cards != 5 else steps // 5 * 5
+    st = steps // max(1, cards) * max(1, cards)
     env.run_random(st, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True)
     if st != steps:
         env.run_random(steps - st, cards_per_launch=1, graph_chunk=0, auto_reset=True)
