@@ -863,7 +863,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe(int64_t n, const ulonglong
 // Parity unpinned: the reference holds no fixture for this layout and Igralec.py cannot be imported
 // (pytorch_lightning, torch_models); tested against a line-cited restatement (oracle/encoder_spec.py).
 //
-// Phase 1, one thread per game: history bytes -> LDS, trick leaders replayed from the cards (the
+// Workgroup = 64 games, 256 threads.  Phase 1, one thread per game (one wave): history bytes -> LDS, trick leaders replayed from the cards (the
 // winner rule of apply_step), initial hand and discards recovered from the planes, the 448 bits of
 // the small fields.  Phase 2, one wave per game at a time: lane t builds row t (an exclusive
 // prefix-OR over the lanes gives "own cards played before"), then the 64 lanes write the 12,544-byte
@@ -884,7 +884,7 @@ __device__ __forceinline__ uint4 bits16_bytes(u32 b) {
 // OR `val` (WIDTH <= 64 bits) into a little-endian bit vector at the compile-time bit offset OFF
 template <int OFF, int NW> __device__ __forceinline__ void bits_insert(u64 (&w)[NW], u64 val) {
     w[OFF / 64] |= val << (OFF % 64);
-    if (OFF % 64 != 0 && OFF / 64 + 1 < NW) w[OFF / 64 + 1] |= val >> (64 - OFF % 64);
+    if constexpr (OFF % 64 != 0 && OFF / 64 + 1 < NW) w[OFF / 64 + 1] |= val >> (64 - OFF % 64);
 }
 // set bit `b` (run-time index) of a bit vector kept in registers
 template <int NW> __device__ __forceinline__ void bits_set(u64 (&w)[NW], u32 b) {
@@ -895,15 +895,17 @@ __device__ __forceinline__ u32 ref_type(u32 c) {    // Nevronski_igralec.tip_igr
     return c == TK_KLOP ? 0u : (has_king(c) ? 1u : ((c == TK_BERAC || c == TK_ODPRTI_BERAC) ? 3u : 2u));
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_observe_ref(int64_t n, const ulonglong2 *__restrict__ s01,
-                                                         const ulonglong2 *__restrict__ s23, const uint8_t *__restrict__ hist,
-                                                         uint4 *__restrict__ rec, int4 *__restrict__ meta) {
-    __shared__ RefDesc desc[TK_BLOCK];
-    __shared__ uint8_t hist_s[TK_BLOCK][48];
-    __shared__ uint8_t rowpos_s[TK_BLOCK / 64][64];
-    __shared__ u64 rowmask_s[TK_BLOCK / 64][64];
+#define OR_GAMES 64                 // games per workgroup: phase 1 on one wave, phase 2 on all four (16 games each)
+__global__ __launch_bounds__(256) void k_observe_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+                                                   const ulonglong2 *__restrict__ s23, const uint8_t *__restrict__ hist,
+                                                   uint4 *__restrict__ rec, int4 *__restrict__ meta) {
+    __shared__ RefDesc desc[OR_GAMES];
+    __shared__ uint8_t hist_s[OR_GAMES][48];
+    __shared__ uint8_t rowpos_s[4][64];
+    __shared__ u64 rowmask_s[4][64];
     u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int64_t base = (int64_t)blockIdx.x * TK_BLOCK;
+    int64_t base = (int64_t)blockIdx.x * OR_GAMES;
+    if (tid < OR_GAMES)
     {   // ---- phase 1
         int64_t i = base + tid;
         bool valid = i < n;
@@ -986,9 +988,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe_ref(int64_t n, const ulong
         }
     }
     __syncthreads();
-    // ---- phase 2: this wave's 64 games, one at a time
-    for (u32 k = 0; k < 64; k++) {
-        u32 gl = wave * 64 + k;
+    // ---- phase 2: this wave's 16 games, one at a time (four waves per 64 games: at 65,536 games that is four
+    // waves per SIMD to hide the stores' issue latency behind each other)
+    for (u32 k = 0; k < OR_GAMES / 4; k++) {
+        u32 gl = wave * (OR_GAMES / 4) + k;
         int64_t gidx = base + gl;
         if (gidx >= n) break;                                             // wave uniform
         const RefDesc &d = desc[gl];
@@ -1036,7 +1039,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe_ref(int64_t n, const ulong
                 u32 rel = o - OR_SMALL_OFF;
                 v = bits16_bytes((u32)(d.small[rel >> 6] >> (rel & 63)) & 0xFFFFu);
             }
-            rec[gidx * (OR_REC / 16) + ch] = v;
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 vv = {v.x, v.y, v.z, v.w};                         // (822 MB per call at 65,536 games: nothing re-reads it from L2)
+            TK_STREAM_STORE(reinterpret_cast<u32x4 *>(rec) + gidx * (OR_REC / 16) + ch, vv);
         }
         __builtin_amdgcn_wave_barrier();                                  // the row buffers are rewritten by the next game
     }
@@ -1983,8 +1988,8 @@ int tarok_observe_ref(tarok_env *e, uint8_t *record_out, int32_t *meta_out, void
     if (!e || !record_out) return TAROK_EINVAL;
     if (!e->hist) return TAROK_EINVAL;                                   // needs a TAROK_HISTORY env
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_observe_ref, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, e->hist,
-                       (uint4 *)record_out, (int4 *)meta_out);
+    hipLaunchKernelGGL(k_observe_ref, dim3((unsigned)((e->n + OR_GAMES - 1) / OR_GAMES)), dim3(256), 0, (hipStream_t)stream, e->n,
+                       e->s01, e->s23, e->hist, (uint4 *)record_out, (int4 *)meta_out);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

@@ -33,6 +33,7 @@ bash tools/sq_counters.sh 4194304 $TAG/sq4m > /dev/null 2>&1 && cp gpurun_out/$T
 python3 tools/krog_stamps.py 65536 $CARDS > $OUT/wave_stamps_65536.txt 2>&1
 python3 tools/card_probe.py 65536 $CARDS > $OUT/card_probe_65536.txt 2>&1
 python3 tools/mlp_time.py 65536 > $OUT/policy_mlp_times.txt 2>&1
+python3 tools/observe_ref_time.py > $OUT/observe_ref_times.txt 2>&1
 # keep only the summaries of the rocprof directories (the raw traces are large)
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 find $OUT/stats_all -name "*kernel_stats.csv" -exec cp {} $OUT/bench_all_modes_kernel_stats.csv \;
