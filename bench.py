@@ -105,6 +105,15 @@ def describe_mode(plan):
     return "tarok_policy_random + tarok_step: two launches per lock-step (what an external policy drives); " + how
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (it travels with the repo); the same words if the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "env steps/sec at 65 536 parallel 4-player games; 1/2/4/8 MI355X"
+
+
 def kernel_src_sha():
     """Hash of the sources libtarokenv.so is built from: what a profile was measured on."""
     from tarok_amd import _native
@@ -254,7 +263,7 @@ def main():
     ep, ss = env.counters()
 
     out = {
-        "metric": "env steps/sec at 65,536 parallel 4-player games; 1/2/4/8 MI355X",
+        "metric": baseline_metric(),
         "value": value, "unit": "env steps/s", "n_gpus": world_size, "steps": plan["launches"], "warmup": wplan["launches"],
         "steps_requested": args.steps, "warmup_requested": args.warmup,
         "ms_per_step": dt / plan["launches"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
