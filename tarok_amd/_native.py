@@ -35,6 +35,10 @@ def hipcc_path():
 
 
 def needs_build():
+    if os.environ.get("TAROK_LIB"):          # an A/B library is whatever its builder made it: never rebuilt over
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("TAROK_LIB=%s does not exist" % LIB_PATH)
+        return False
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)

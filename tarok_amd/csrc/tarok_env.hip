@@ -55,6 +55,12 @@
 #endif
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
+// wave-uniform branches of the card loop (play_role; EARLY_LINES = its one-wave-per-SIMD build): a taken branch
+// costs a lone wave ~25 cycles, one that falls through ~7 (tools/valu_issue: br_taken / br_not) — the usual path
+// is laid out as the fall-through.  Not in the 128-VGPR build: four waves hide a branch, and the block order
+// the hints give it puts spills into the scoring drain (4 M games: -12 %).
+#define TK_RARE(c) (EARLY_LINES ? __builtin_expect(!!(c), 0) : !!(c))
+#define TK_USUAL(c) (EARLY_LINES ? __builtin_expect(!!(c), 1) : !!(c))
 
 // Per-slot side record: TK_AHEAD (fourteen) 64-byte next-game lines.  Line b holds the dealt-ahead
 // game whose episode number is b mod TK_AHEAD: its packed pairs, its RNG key and the episode number
@@ -102,7 +108,7 @@ struct tarok_env {
     u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
-    bool wide_regs;          // the 256-VGPR build of the multi-card kernel (batches of at most two play waves per SIMD)
+    bool wide_regs;          // the no-spill build of the Bot-policy kernel (k_play_wide)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -372,8 +378,9 @@ template <bool D> __device__ __forceinline__ int (*sacc_storage())[TK_BLOCK] {
 // Play role of a step launch for the 256 slots of play workgroup `group`: thread `tid` (0..255)
 // plays slot group * 256 + tid; threads with active = false (a larger workgroup's extra threads)
 // only take part in the two barriers.  The card comes from action_in, or (action_in == NULL) from
-// a_reg, or with RANDOM from the in-kernel Bot policy.
-template <bool RANDOM, bool HIST>
+// a_reg, or with RANDOM from the in-kernel Bot policy.  EARLY_LINES: where the trick-aligned loops fetch the
+// lines of a lane's third and later games of a launch (see TOP_UP_EARLY below).
+template <bool RANDOM, bool HIST, bool EARLY_LINES = false>
 __device__ __forceinline__ void play_role(
     u32 group, u32 tid, bool active, u32 a_reg,
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 count, u32 *epoch,
@@ -452,25 +459,31 @@ __device__ __forceinline__ void play_role(
     u32 allowed = TK_AHEAD - min(cprev0, (u32)TK_AHEAD);
     int4 acc = make_int4(0, 0, 0, 0);
     u32 cur_ep = 0;
-    // (na, nb, nkey): the next game (episode cur_ep + 1), (na2, nb2, nkey2): the one after it; both
-    // are loaded here, before the loop: a load still in flight across loop iterations would make
-    // every iteration wait for the previous iteration's stores (vmcnt counts both, in order)
+    // (na, nb, nkey, nep1): the line of the next game (episode cur_ep + 1), (na2, nb2, nkey2, nep2): of the
+    // one after it.  ok1 / ok2: the line is usable.  EARLY_LINES: ... has been requested (and was one this
+    // launch may take); its episode tag is compared when it is taken, so that nothing waits for the load
+    // where it is issued (line_tag).  Both are loaded here, before the loop, and topped up at the first
+    // card of a trick (below) — never across the loop's back edge: a load in flight there would make every
+    // iteration wait for the previous iteration's stores (vmcnt counts both, in order)
     ulonglong2 na = make_ulonglong2(0, 0), nb = na, na2 = na, nb2 = na;
     u64 nkey = 0, nkey2 = 0;
+    u32 nep1 = 0, nep2 = 0;
     bool ok1 = false, ok2 = false;
+    auto line_tag = [&](bool &ok, u32 &nep, u32 tag, u32 want) __attribute__((always_inline)) {
+        if constexpr (EARLY_LINES) { nep = tag; ok = true; } else ok = tag == want;
+    };
     if (spec) {
         acc = cnt[i].score_sum;
         cur_ep = cnt[i].episode;
         if (autoreset && allowed > 0) {
             const AuxLine *ln = &aux[i].line[TK_LINE(g.epar + 1)];
             na = ln->n01; nb = ln->n23; nkey = ln->nkey;
-            u32 nep = ln->nep, nep2 = 0xFFFFFFFFu;
+            line_tag(ok1, nep1, ln->nep, cur_ep + 1);
             if (allowed > 1 && cards > 4) {          // a Berac can be over after 4 cards
                 const AuxLine *l2 = &aux[i].line[TK_LINE(g.epar + 2)];
-                na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey; nep2 = l2->nep;
+                na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
+                line_tag(ok2, nep2, l2->nep, cur_ep + 2);
             }
-            ok1 = nep == cur_ep + 1;
-            ok2 = nep2 == cur_ep + 2;
         }
     }
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
@@ -479,10 +492,14 @@ __device__ __forceinline__ void play_role(
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
 #ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
-    u32 ev_deal = 0, ev_lazy = 0, ev_renew = 0;
+    u32 ev_deal = 0, ev_lazy = 0, ev_renew = 0, ev_early = 0;
 #endif
 #ifdef TK_CARD_STAMPS
-    u32 cs_012 = 0, cs_3 = 0;
+    u32 cs_012 = 0, cs_3 = 0, cs_seg[4] = {0, 0, 0, 0};      // cs_seg: the 4th card's rules | scoring queue | renewal | outputs
+    u64 cs_t = 0;
+#define TK_SEG(k) do { if constexpr (ALL && NT == 3) { u64 t_ = __builtin_amdgcn_s_memtime(); cs_seg[k] += (u32)(t_ - cs_t); cs_t = t_; } } while (0)
+#else
+#define TK_SEG(k) do { } while (0)
 #endif
     bool resync = false;                    // a line that should have been usable was not: refill them all
     bool blocked = false;                   // a game was dealt in place: no more swap-ins in this launch
@@ -490,6 +507,26 @@ __device__ __forceinline__ void play_role(
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+    // which of its two line buffers a lane could fill now (-> lacks: the next game's, lacks2: the one after it);
+    // returns lacks.  `consumed >= 1`: before that, what the loads above could not take is not to be had.
+    auto lines_lacking = [&](bool &lacks, bool &lacks2) __attribute__((always_inline)) {
+        bool base = spec && !blocked && consumed >= 1;
+        lacks = base && !ok1 && consumed < allowed;
+        lacks2 = base && !ok2 && consumed + 1 < allowed;
+        return lacks;
+    };
+    auto fetch_lines = [&](bool lacks, bool lacks2) __attribute__((always_inline)) {
+        if (lacks) {
+            const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
+            na = ln->n01; nb = ln->n23; nkey = ln->nkey;
+            line_tag(ok1, nep1, ln->nep, cur_ep + 1);
+        }
+        if (lacks2) {
+            const AuxLine *l2 = &aux[i].line[TK_LINE(cur_ep + 2)];
+            na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
+            line_tag(ok2, nep2, l2->nep, cur_ep + 2);
+        }
+    };
     auto play_card = [&](auto all_tag, auto nt_tag, auto std_tag, int64_t row, int ci) __attribute__((always_inline)) {
         // ALL: every lane of the wave is a valid slot with a game in play (wave uniform, see below):
         // no per-lane predicates around the rules and the output stores.
@@ -501,8 +538,29 @@ __device__ __forceinline__ void play_role(
         constexpr int NT = decltype(nt_tag)::value;
         constexpr bool STD = decltype(std_tag)::value;
         if constexpr (NT >= 0) g.nt = (u32)NT;
+        // EARLY_LINES (the one-wave-per-SIMD build), trick-aligned loops: the lines of the next games are topped
+        // up HERE, at the first card of a trick, as soon as one lane has used its two up — three cards (~1,400
+        // cycles) before a game can end and take one: the memory round trip hides behind the rules, and the
+        // compiler's wait at the first use counts past the stores issued since.  (A lane's `consumed` only moves
+        // at a 4th card, so a lane that still lacks a line at the 4th card could not have fetched one: no fetch
+        // on the spot in these loops.)  With four waves on a SIMD the other waves hide the round trip of a
+        // fetch on the spot, and the earlier, more frequent top-ups only cost instructions (4 M games: -11 %).
+        constexpr bool TOP_UP_EARLY = EARLY_LINES && ALL && NT == 0;
+        constexpr bool TOP_UP_LATE = !(EARLY_LINES && ALL && NT == 3);
+        if constexpr (TOP_UP_EARLY) {
+            bool lacks = false, lacks2 = false;
+            if (TK_RARE(__ballot(lines_lacking(lacks, lacks2)) != 0)) {
+#ifdef TK_EVENT_STAMPS
+                ev_early++;
+#endif
+                fetch_lines(lacks, lacks2);
+            }
+        }
         const bool v = ALL ? true : valid;
         const bool play = ALL ? true : (valid && g.phase == TK_PHASE_PLAY);
+#ifdef TK_CARD_STAMPS
+        if constexpr (ALL && NT == 3) cs_t = __builtin_amdgcn_s_memtime();
+#endif
         u32 a = a_in;
         if (RANDOM) a = play ? policy_action(key, g.trick_no * 4 + g.nt, legal) : 255u;
         u64 scores = 0;
@@ -522,12 +580,13 @@ __device__ __forceinline__ void play_role(
             if (RANDOM && (STD || action_out)) TK_STREAM_STORE(&action_out[row], (uint8_t)a);
             if (!STD && trick) TK_STREAM_STORE(&trick[row], (uint16_t)trick_info);
         }
+        TK_SEG(0);
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
         if constexpr (CAN_END && DEFER) {
             u64 fm = __ballot(fin);
-            if (fm) {                                                     // (wave uniform)
-                if (fq_n >= 64) drain_finished(64);                       // room for 64 more: fewer than 64 wait now
+            if (TK_USUAL(fm != 0)) {                                      // (wave uniform)
+                if (TK_RARE(fq_n >= 64)) drain_finished(64);                       // room for 64 more: fewer than 64 wait now
                 if (fin) {
                     u32 e = (fq_head + fq_n + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
                     fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
@@ -539,6 +598,7 @@ __device__ __forceinline__ void play_role(
                 fq_n += (u32)__popcll(fm);
             }
         }
+        TK_SEG(1);
         if (CAN_END && !DEFER && fin) {
             if (reward) {
                 u64 rs = scores;
@@ -557,36 +617,31 @@ __device__ __forceinline__ void play_role(
         }
         if (CAN_END && (ALL || autoreset)) {                 // (ALL implies auto-reset, and every lane was in play: done = just finished)
             bool renew = ALL ? fin : (v && g.phase == TK_PHASE_DONE);
-            if (__ballot(renew)) {
+            if (TK_USUAL(__ballot(renew) != 0)) {
 #ifdef TK_EVENT_STAMPS
                 ev_renew++;
-                if (__ballot(renew && !blocked && !ok1 && consumed >= 1 && consumed < allowed)) ev_lazy++;
 #endif
-                // A third or later game of a launch (the two preloaded lines are used up) is fetched on the spot:
-                // a memory round trip (~550 cycles) that nothing hides.  So when one lane has to, EVERY lane that
-                // has used its preloaded lines up takes its next game's line along — finishing or not: the one
-                // wait serves them all, and most lanes hold their line by the time they finish.
-                // (and the line after it, into the second buffer)
-                bool lacks = spec && !blocked && !ok1 && consumed >= 1 && consumed < allowed;
-                if (__ballot(renew && lacks)) {
-                    bool lacks2 = spec && !blocked && !ok2 && consumed >= 1 && consumed + 1 < allowed;
-                    if (lacks) {
-                        const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
-                        na = ln->n01; nb = ln->n23; nkey = ln->nkey;
-                        ok1 = ln->nep == cur_ep + 1;
+                // Loops that are not trick-aligned: a third or later game of a launch (the two preloaded lines
+                // are used up) is fetched on the spot: a memory round trip (~550 cycles) that nothing hides.  So
+                // when one lane has to, EVERY lane that has used its lines up takes its next games' lines along —
+                // finishing or not: the one wait serves them all.
+                if constexpr (TOP_UP_LATE) {
+                    bool lacks = spec && !blocked && !ok1 && consumed >= 1 && consumed < allowed;
+                    if (TK_RARE(__ballot(renew && lacks) != 0)) {
+#ifdef TK_EVENT_STAMPS
+                        ev_lazy++;
+#endif
+                        bool lacks2 = spec && !blocked && !ok2 && consumed >= 1 && consumed + 1 < allowed;
+                        fetch_lines(lacks, lacks2);
+                        TK_WAIT_LOADS();
                     }
-                    if (lacks2) {
-                        const AuxLine *l2 = &aux[i].line[TK_LINE(cur_ep + 2)];
-                        na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
-                        ok2 = l2->nep == cur_ep + 2;
-                    }
-                    TK_WAIT_LOADS();
                 }
-                bool swap = renew && !blocked && ok1;
+                bool swap = renew && !blocked && ok1 && (!EARLY_LINES || nep1 == cur_ep + 1);
                 if (swap) {
                     unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game, cprev = 0
                     key = nkey;
                     na = na2; nb = nb2; nkey = nkey2;
+                    if constexpr (EARLY_LINES) nep1 = nep2;
                     ok1 = ok2 && consumed + 1 < allowed;
                     ok2 = false;
                 }
@@ -596,7 +651,7 @@ __device__ __forceinline__ void play_role(
                 if (deal_here && consumed < allowed) resync = true;
                 if (deal_here) blocked = true;
                 u64 pend = __ballot(deal_here);
-                if (pend) {
+                if (TK_RARE(pend != 0)) {
 #ifdef TK_EVENT_STAMPS
                     ev_deal += (u32)__popcll(pend);
 #endif
@@ -625,12 +680,14 @@ __device__ __forceinline__ void play_role(
                 if (renew) { cur_ep++; consumed++; seats_dirty = true; }
             }
         }
+        TK_SEG(2);
         // (ALL: a finished game has been replaced just above, so every lane is in play again)
         if (RANDOM) legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
         if (v) {
             TK_STREAM_STORE(&obs[row], RANDOM ? obs_word_with<ALL>(g, fin, legal) : obs_word(g, fin));
             if (STD || done) TK_STREAM_STORE(&done[row], (uint8_t)(fin ? 1 : 0));
         }
+        TK_SEG(3);
     };
     // With auto-reset a lane that is in play stays in play (a finished game is replaced within the
     // same card), so "every lane of the wave valid and in play" decided HERE holds for the whole
@@ -705,43 +762,47 @@ __device__ __forceinline__ void play_role(
         stamps[3 * w + 2] = ((__builtin_amdgcn_s_memtime() - t_cyc0) << 32) | (t_play & 0xFFFFFFFFULL);
 #ifdef TK_CARD_STAMPS
         stamps[3 * w + 0] = ((u64)cs_012 << 32) | (u64)cs_3;
+        stamps[3 * w + 1] = ((u64)cs_seg[0] << 32) | (u64)cs_seg[1];
+        stamps[3 * w + 2] = (stamps[3 * w + 2] & 0xFFFFFFFFULL) | ((u64)cs_seg[2] << 32);      // (cs_seg[3] = cs_3 - the others)
 #endif
 #ifdef TK_EVENT_STAMPS                      // (replaces the entry time stamp)
-        stamps[3 * w + 0] = ((u64)ev_deal << 48) | ((u64)ev_lazy << 32) | ((u64)ev_renew << 16) | (u64)__popcll(__ballot(consumed > 0));
+        stamps[3 * w + 0] = ((u64)ev_deal << 48) | ((u64)ev_lazy << 32) | ((u64)ev_renew << 16) | (u64)ev_early;
 #endif
     }
 }
 
-// Two register budgets of the same kernel.  WIDE = false: at most 128 VGPRs, four waves per SIMD — the
-// throughput-bound batch sizes (the specialised card loops want a few more and spill a little).  WIDE = true:
-// up to 256 VGPRs, for batches that put no more than two play waves on a SIMD anyway (up to 131,072 games:
-// the BASELINE size has one) — nothing spills inside the card loops, where a scratch reload is a memory
-// round trip that nothing hides.  HIST: also record the play history (one byte per card; tarok_create flag
-// TAROK_HISTORY).
+// Two register budgets of the same kernel.  WIDE = true (the Bot-policy launches, every batch size): ~165 VGPRs,
+// nothing spills inside the card loops — still three waves per SIMD, and where the batch puts one wave on a
+// SIMD (65,536 games) a scratch reload would be a memory round trip that nothing hides; the next games' lines are
+// topped up early and the usual path falls through its branches (EARLY_LINES in play_role).  WIDE = false: at
+// most 128 VGPRs (the specialised card loops spill a little), four waves per SIMD: the external-action step,
+// and the Bot-policy build of rounds 1-2a that TAROK_WIDE_REGS=0 still selects for A/B runs (same-box medians,
+// G steps/s, wide | narrow: 262,144 games 160.9 | 155.3, 1 M 163.9 | 146.0, 4 M 175.9 | 169.3).
+// HIST: also record the play history (one byte per card; tarok_create flag TAROK_HISTORY).
 #define TK_PLAY_ARGS                                                                                                             \
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,         \
         const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
         ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
         u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps
-template <bool RANDOM, bool HIST>
+template <bool RANDOM, bool HIST, bool WIDE>
 __device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
     else
-        play_role<RANDOM, HIST>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
+        play_role<RANDOM, HIST, WIDE>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
                                 action_in, action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
 }
 #define TK_PLAY_FWD n, seed, offset, mix, flags, cards, stride, play_groups, epoch, fan, action_in, action_out, reward, done, trick, obs, \
                     hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps
 template <bool RANDOM, bool HIST>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(TK_PLAY_ARGS) {
-    play_kernel_body<RANDOM, HIST>(TK_PLAY_FWD);
+    play_kernel_body<RANDOM, HIST, false>(TK_PLAY_FWD);
 }
 template <bool RANDOM, bool HIST>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_play_wide(TK_PLAY_ARGS) {
-    play_kernel_body<RANDOM, HIST>(TK_PLAY_FWD);
+    play_kernel_body<RANDOM, HIST, true>(TK_PLAY_FWD);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1752,7 +1813,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
-    e->wide_regs = n_games <= 2 * 1024 * 64;                  // 1,024 SIMDs x 64 lanes x 2 waves
+    e->wide_regs = true;                                      // (see k_play_wide)
     if (const char *f = getenv("TAROK_WIDE_REGS")) e->wide_regs = atoi(f) != 0;      // diagnostics (A/B runs)
     if (const char *f = getenv("TAROK_REFILL_FAN")) { int v = atoi(f); if (v >= 1 && v <= TK_REFILL_FAN) e->refill_fan = (uint32_t)v; }
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);

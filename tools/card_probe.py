@@ -22,16 +22,21 @@ for mixname, mix in (("all", K.MIX_ALL), ("klop", 16)):
     nw = n // 64
     st = torch.zeros((nw, 3), dtype=torch.int64, device="cuda")
     _native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
-    a012, a3, tot = [], [], []
+    a012, a3, tot, s0, s1, s2 = [], [], [], [], [], []
     for it in range(8):
         env.krog_random(cards, auto_reset=True)
         torch.cuda.synchronize()
         a = st.cpu().numpy().view(np.uint64)
         a012.append((a[:, 0] >> np.uint64(32)).astype(np.int64)); a3.append((a[:, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64))
         tot.append((a[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        s0.append((a[:, 1] >> np.uint64(32)).astype(np.int64)); s1.append((a[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64))
+        s2.append((a[:, 2] >> np.uint64(32)).astype(np.int64))
     a012, a3, tot = np.concatenate(a012), np.concatenate(a3), np.concatenate(tot)
+    s0, s1, s2 = np.concatenate(s0), np.concatenate(s1), np.concatenate(s2)
     tr = cards // 4
     print("%s: per trick, median over waves: cards 0-2 %.0f cycles (%.0f per card), 4th card %.0f cycles; play part of the launch %.0f cycles "
           "= %.0f per trick (stamps included)" % (mixname, np.median(a012) / tr, np.median(a012) / tr / 3, np.median(a3) / tr, np.median(tot), np.median(tot) / tr))
+    print("    the 4th card: rules + action store %.0f | scoring queue (push, drain) %.0f | renewal (swap-in) %.0f | legal mask, observation, stores %.0f"
+          "   (each with one s_memtime)" % (np.median(s0) / tr, np.median(s1) / tr, np.median(s2) / tr, np.median(a3 - s0 - s1 - s2) / tr))
     _native.check(env.L.tarok_debug_stamps(env._h, None))
     env.close()

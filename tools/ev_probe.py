@@ -33,6 +33,6 @@ for it in range(8):
 play = np.concatenate([r[0] for r in rows]); deal = np.concatenate([r[1] for r in rows]); lazy = np.concatenate([r[2] for r in rows])
 renew = np.concatenate([r[3] for r in rows]); cons = np.concatenate([r[4] for r in rows])
 print("play cycles: median %d p90 %d max %d" % (np.median(play), np.percentile(play, 90), play.max()))
-print("waves with deal_here lanes: %.3f  (mean lanes %.3f)   lazy fetch events per wave: mean %.2f   renew events: mean %.2f   lanes consuming: mean %.1f" % ((deal > 0).mean(), deal.mean(), lazy.mean(), renew.mean(), cons.mean()))
-for name, x in (("deal", deal), ("lazy", lazy), ("renew", renew), ("cons", cons)):
+print("waves with deal_here lanes: %.3f  (mean lanes %.3f)   fetches on the spot per wave: mean %.2f   renew events: mean %.2f   early top-ups per wave: mean %.2f" % ((deal > 0).mean(), deal.mean(), lazy.mean(), renew.mean(), cons.mean()))
+for name, x in (("deal", deal), ("lazy", lazy), ("renew", renew), ("early", cons)):
     print(name, "corr with play cycles %.3f" % np.corrcoef(x, play)[0, 1], " by value:", {int(v): int(np.median(play[x == v])) for v in np.unique(x)[:8]})

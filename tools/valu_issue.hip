@@ -55,6 +55,16 @@ typedef uint32_t u32;
 #define I_snop(r)       "s_nop 0\n"
 #define I_sand(r)       "s_and_b64 s[10:11], s[10:11], exec\n"
 #define I_sadd(r)       "s_add_u32 s12, s12, 1\n"
+// branches (the 1: label is the next instruction but one: a taken branch skips one s_nop).  br_taken: 2
+// instructions executed per copy, br_not: 3, execz (not taken): 2, saveexec (the compiler's `if` on a per-lane
+// condition: s_and_saveexec, s_cbranch_execz not taken, body, s_or exec): 4, ballot_br (the `if (__ballot(c))` shape:
+// v_cmp into an SGPR pair, s_cmp_lg_u64, s_cbranch_scc1 taken): 3, ballot_nobr (the same, not taken): 4
+#define I_br_taken(r)    "s_cmp_eq_u32 s12, s12\ns_cbranch_scc1 1f\ns_nop 0\n1:\n"
+#define I_br_not(r)      "s_cmp_eq_u32 s12, s12\ns_cbranch_scc0 1f\ns_nop 0\n1:\n"
+#define I_execz(r)       "s_cbranch_execz 1f\ns_nop 0\n1:\n"
+#define I_saveexec(r)    "s_and_saveexec_b64 s[10:11], exec\ns_cbranch_execz 1f\ns_nop 0\n1:\ns_or_b64 exec, exec, s[10:11]\n"
+#define I_ballot_br(r)   "v_cmp_ge_u32 s[10:11], " r ", " r "\ns_cmp_lg_u64 s[10:11], 0\ns_cbranch_scc1 1f\ns_nop 0\n1:\n"
+#define I_ballot_nobr(r) "v_cmp_ge_u32 s[10:11], " r ", " r "\ns_cmp_lg_u64 s[10:11], 0\ns_cbranch_scc0 1f\ns_nop 0\n1:\n"
 // 64-bit forms (r = a VGPR pair)
 #define I_lshl64(r)     "v_lshlrev_b64 " r ", 1, " r "\n"
 #define I_lshl64v(r)    "v_lshlrev_b64 " r ", %8, " r "\n"
@@ -106,7 +116,8 @@ struct Rec { u64 cycles, real; u32 hw_id, xcc; };
 #define OP32(X) \
     X(and, 1) X(xor, 1) X(or3, 1) X(add, 1) X(add3, 1) X(lshr, 1) X(lshl_or, 1) X(mov, 1) X(bitop3, 1) X(bcnt, 1) X(bfe, 1) \
     X(min, 1) X(max, 1) X(mul_lo, 1) X(mul_hi, 1) X(mul_u24, 1) X(mad_u24, 1) X(cndmask, 1) X(cmp, 1) X(cmp_vcc, 1)          \
-    X(readlane, 1) X(sdwa, 1) X(fma, 1) X(snop, 1) X(sand, 1) X(sadd, 1) X(select, 3)
+    X(readlane, 1) X(sdwa, 1) X(fma, 1) X(snop, 1) X(sand, 1) X(sadd, 1) X(select, 3)                                       \
+    X(br_taken, 2) X(br_not, 3) X(execz, 2) X(saveexec, 4) X(ballot_br, 3) X(ballot_nobr, 4)
 #define OP64(X) X(lshl64, 1) X(lshl64v, 1) X(lshr64, 1) X(lshl_add64, 1) X(mov64, 1) X(mad64, 1)
 
 #define DEF32(n, k) KERNEL(k32_##n##_ind, u32, REP8(IND8(I_##n))) KERNEL(k32_##n##_dep, u32, REP8(DEP8(I_##n)))
@@ -178,6 +189,7 @@ static Result run(const Op &op, bool dep, int wps, int lanes, int iters, Rec *d_
 
 int main(int argc, char **argv) {
     int iters = argc > 1 ? atoi(argv[1]) : 1500;
+    const char *only = argc > 2 ? argv[2] : nullptr;          // comma-separated op names (default: all)
     CHK(hipSetDevice(0));
     Rec *d_out;
     CHK(hipMalloc((void **)&d_out, 8192 * sizeof(Rec)));
@@ -186,8 +198,11 @@ int main(int argc, char **argv) {
     printf("{\n \"iters\": %d, \"instructions_per_iteration\": %d,\n \"unit\": \"shader cycles (s_memtime) per wave-instruction, median over the waves\",\n \"ops\": {\n", iters, PER_ITER);
     size_t nops = sizeof(g_ops) / sizeof(g_ops[0]);
     double clock_sum = 0; int clock_n = 0;
+    bool first = true;
     for (size_t o = 0; o < nops; o++) {
-        printf("  \"%s\": {", g_ops[o].name);
+        if (only && !strstr((std::string(",") + only + ",").c_str(), (std::string(",") + g_ops[o].name + ",").c_str())) continue;
+        printf("%s  \"%s\": {", first ? "" : ",\n", g_ops[o].name);
+        first = false;
         for (int dep = 0; dep < 2; dep++) {
             printf("\"%s\": {", dep ? "dep" : "ind");
             for (int k = 0; k < 4; k++) {
@@ -198,10 +213,10 @@ int main(int argc, char **argv) {
             }
             printf("}%s", dep ? "" : ", ");
         }
-        printf("}%s\n", o + 1 < nops ? "," : "");
+        printf("}");
         fflush(stdout);
     }
-    printf(" },\n \"half_waves\": {\n");
+    printf("\n },\n \"half_waves\": {\n");
     // does a wave with 32 active lanes issue in fewer cycles?  (lanes: 1 = low half only, 2 = even lanes)
     const char *probe[] = {"and", "bcnt", "mul_lo", "lshl64", "cndmask", "bitop3"};
     for (size_t p = 0; p < 6; p++) {
