@@ -84,6 +84,9 @@ template <class F> constexpr u32 tk_tt(F f) { return f(0xF0u, 0xCCu, 0xAAu) & 0x
 #define TK_BITOP3(a, b, c, ...) ((u32)__builtin_amdgcn_bitop3_b32((a), (b), (c), tk_tt([](u32 a_, u32 b_, u32 c_) { return (__VA_ARGS__); })))
 #define TK_LO(x) ((u32)(x))
 #define TK_HI(x) ((u32)((x) >> 32))
+#ifndef TK_KEEP_VGPR                         // value materialised in a VGPR here (the CPU build of the tests defines it away)
+#define TK_KEEP_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 #define TK_U64(lo, hi) (((u64)(u32)(hi) << 32) | (u64)(u32)(lo))
 
 __device__ __forceinline__ u64 seat_cards(const Game &g, u32 s) {
@@ -407,22 +410,27 @@ __device__ __forceinline__ u32 rng32(u32 lo, u32 hi, u32 i) {
 __device__ __forceinline__ u32 rng32(u64 key, u32 i) { return rng32((u32)key, (u32)(key >> 32), i); }
 __device__ __forceinline__ u32 pick(u32 r, u32 n) { return __umulhi(r, n); }
 
-// index of the k-th (0-based) set bit, k < popcount(m): bisection on the popcount of a bit
-// field (v_bfe + v_bcnt per level), the window's position carried instead of a shifted copy
+// index of the k-th (0-based) set bit, k < popcount(m): the smallest p with more than k set bits at or below
+// it, by bisection on p, one bit of p per level, without a compare or a select (on gfx950 a v_cndmask needs two
+// idle slots after the v_cmp that made its mask, and a lone wave pays for them): v_bcnt adds ~k to its count, so
+// the sign of the sum says "count <= k", and a funnel shift (v_alignbit) moves that sign into p.
+// Per level: v_lshl_or (the candidate), v_bfe (the bits below it), v_bcnt, v_alignbit; 26 instructions in all
+// (the bisection that carried the remaining k along and selected on compares: 41).
 __device__ __forceinline__ u32 kth_bit(u64 m, u32 k) {
-    u32 c = __popc(TK_LO(m));
-    bool up = k >= c;
-    u32 w = up ? TK_HI(m) : TK_LO(m);
-    k = up ? k - c : k;
-    u32 pos = 0;
+    u32 lo = TK_LO(m), hi = TK_HI(m);
+    u32 nk = ~k;                                     // count + nk is negative  <=>  count <= k
+    u32 c = (u32)__popc(lo);
+    u32 s0 = (u32)((int)(c + nk) >> 31);             // all ones: the bit is in the high word
+    u32 w = TK_BITOP3(lo, hi, s0, (a_ & ~c_) | (b_ & c_));
+    nk += c & s0;                                    // (~(k - c) = ~k + c)
+    u32 p = ((u32)__popc(w & 0xFFFFu) + nk) >> 31;   // p = position / 16
 #pragma unroll
-    for (u32 half = 16; half >= 1; half >>= 1) {
-        u32 cc = __popc(__builtin_amdgcn_ubfe(w, pos, half));
-        bool go = k >= cc;
-        k = go ? k - cc : k;
-        pos += go ? half : 0u;
+    for (int s = 3; s >= 0; s--) {                   // p = position / 2^s after the level
+        u32 q = (p << (s + 1)) | (1u << s);
+        u32 d = (u32)__popc(__builtin_amdgcn_ubfe(w, 0, q)) + nk;
+        p = (p << 1) | (d >> 31);
     }
-    return pos + (up ? 32u : 0u);
+    return p | (s0 & 32u);
 }
 
 // uniform card among the legal ones (Bot_igralec.igraj_karto, Igralec.py:158-159)

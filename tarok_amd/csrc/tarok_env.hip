@@ -790,9 +790,13 @@ __device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
-    else
+    else {
+#ifdef TK_PLAY_PRIO
+        __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
+#endif
         play_role<RANDOM, HIST, WIDE>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
                                 action_in, action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
+    }
 }
 #define TK_PLAY_FWD n, seed, offset, mix, flags, cards, stride, play_groups, epoch, fan, action_in, action_out, reward, done, trick, obs, \
                     hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps

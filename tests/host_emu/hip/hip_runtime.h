@@ -15,6 +15,7 @@ static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // v_bfe_u32: (src >> offset[4:0]) & ((1 << width[4:0]) - 1)
+#define TK_KEEP_VGPR(x) ((void)0)
 static inline unsigned __builtin_amdgcn_ubfe(unsigned s, unsigned off, unsigned w) {
     off &= 31; w &= 31;
     return w ? (s >> off) & ((1u << w) - 1) : 0;
