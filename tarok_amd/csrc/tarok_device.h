@@ -63,6 +63,21 @@ __device__ __forceinline__ void unpack(Game &g, u64 x0, u64 x1, u64 y0, u64 y1) 
     g.team = m3 & 15; g.epar = (m3 >> 4) & 15; g.cprev = (m3 >> 8) | ((m2 >> 8) << 2);
 }
 
+// The same for a line of the dealt-ahead buffer: a game at its first card (deal_into_buffer: setup_game, Bot
+// exchange), so no card of a trick and nothing to re-deal.  Written as constants: where the caller is at the end
+// of a trick of EVERY lane (the trick-aligned card loops) "no card led" stays a compile-time fact across the
+// swap, and the next legal mask is the leader's (the hand, pagat rule) without the follow-suit selects.
+__device__ __forceinline__ void unpack_fresh(Game &g, u64 x0, u64 x1, u64 y0, u64 y1) {
+    g.C = x0 & TK_DECK; g.A = y0 & TK_DECK; g.B = y1 & TK_DECK;
+    u32 m0 = (u32)(x0 >> 54), m2 = (u32)(y0 >> 54), m3 = (u32)(y1 >> 54);
+    g.nt = 0; g.leader = (m0 >> 2) & 3; g.trick_no = (m0 >> 4) & 15; g.phase = m0 >> 8;
+    g.talon = x1 & ((1ULL << 36) - 1);
+    g.trick = 0;
+    g.tl = (u32)(x1 >> 60) & 7; g.error = (u32)(x1 >> 63);
+    g.contract = m2 & 15; g.declarer = (m2 >> 4) & 3; g.king = (m2 >> 6) & 3;
+    g.team = m3 & 15; g.epar = (m3 >> 4) & 15; g.cprev = 0;
+}
+
 __device__ __forceinline__ void pack_play(const Game &g, u64 &x0, u64 &x1) {
     x0 = g.C | ((u64)(g.nt | (g.leader << 2) | (g.trick_no << 4) | (g.phase << 8)) << 54);
     x1 = g.talon | ((u64)g.trick << 36) | ((u64)g.tl << 60) | ((u64)g.error << 63);

@@ -638,7 +638,7 @@ __device__ __forceinline__ void play_role(
                 }
                 bool swap = renew && !blocked && ok1 && (!EARLY_LINES || nep1 == cur_ep + 1);
                 if (swap) {
-                    unpack(g, na.x, na.y, nb.x, nb.y);        // carries epar of the new game, cprev = 0
+                    unpack_fresh(g, na.x, na.y, nb.x, nb.y);  // carries epar of the new game
                     key = nkey;
                     na = na2; nb = nb2; nkey = nkey2;
                     if constexpr (EARLY_LINES) nep1 = nep2;
