@@ -171,22 +171,30 @@ __device__ __forceinline__ int prestej(u64 m) {
 // nothing else is allowed" (the over-play filter there is dead code).
 // The suits are the low word of a plane and the taroks (pagat = bit 0) the high word, so the
 // rule is written on the halves: lead-suit cards if any, else taroks if any, else the hand.
-__device__ __forceinline__ u64 legal_mask(u64 hand, bool has_lead, u32 lead, bool klopfam) {
+// Written on word masks, not on compares and selects: on gfx950 a select costs a lone wave 16.6 cycles through a
+// compare (v_cmp, two idle slots, v_cndmask), 28.5 on a compound condition (v_cmp, s_and, v_cndmask) and 12.5 as
+// three plain vector instructions (tools/valu_issue: cmpsel / select / arithsel).
+// all ones where x == 0, in two plain vector instructions: v_sad_u8 sums the four bytes of x onto -1, the sign
+// of that is smeared over the word.  (Written as min(x, 1) or as a sign trick of x itself the compiler turns it
+// back into the compare and the select; it does not look into v_sad_u8.)
+__device__ __forceinline__ u32 tk_zero_mask(u32 x) { return (u32)((int)__builtin_amdgcn_sad_u8(x, 0u, ~0u) >> 31); }
+__device__ __forceinline__ u64 legal_mask(u64 hand, bool has_lead, u32 lead, u32 contract) {
     u32 hl = TK_LO(hand), hh = TK_HI(hand);
-    u32 sm = lead < 32 ? (0xFFu << (lead & 24)) : 0u;   // a tarok lead: no suit to follow, taroks next
-    u32 s = hl & sm;
-    bool has_s = has_lead && s != 0;
-    bool has_t = has_lead && hh != 0;
-    u32 bl = has_s ? s : (has_t ? 0u : hl);
-    u32 bh = has_s ? 0u : hh;
-    u32 nh = bh & ~1u;                                  // without the pagat
-    bool drop = klopfam && (bl | nh) != 0;
-    return TK_U64(bl, drop ? nh : bh);
+    u32 lm = has_lead ? ~0u : 0u;                       // (a compile-time fact in the trick-aligned card loops)
+    u32 tarok_led = (u32)((int)(lead << 26) >> 31);     // bit 5 of the id: no suit to follow, taroks next
+    u32 s = TK_BITOP3(hl, 0xFFu << (lead & 24), tarok_led, a_ & b_ & ~c_) & lm;
+    u32 zs = tk_zero_mask(s);                           // no card of the suit led (or nobody led)
+    u32 zt = tk_zero_mask(hh) | ~lm;                    // no taroks (or nobody led)
+    u32 bl = s | TK_BITOP3(hl, zs, zt, a_ & b_ & c_);
+    u32 bh = hh & zs;
+    u32 kf = (0x281u >> contract) & 1u;                 // Klop, Berac, Odprti berac: the pagat only when nothing else goes
+    u32 only_pagat = tk_zero_mask(bl | (bh & ~1u));
+    return TK_U64(bl, TK_BITOP3(bh, kf, only_pagat, a_ & ~(b_ & ~c_)));
 }
 
 __device__ __forceinline__ u64 legal_now(const Game &g) {
     u32 seat = (g.leader + g.nt) & 3;
-    return legal_mask(hand_of(g, seat), g.nt != 0, g.trick & 63, klop_family(g.contract));
+    return legal_mask(hand_of(g, seat), g.nt != 0, g.trick & 63, g.contract);
 }
 
 // observation word (tarok_env.h TAROK_OBS_*) from an already computed legal mask

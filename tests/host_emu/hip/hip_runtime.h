@@ -16,6 +16,14 @@ static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // v_bfe_u32: (src >> offset[4:0]) & ((1 << width[4:0]) - 1)
 #define TK_KEEP_VGPR(x) ((void)0)
+// v_sad_u8: sum of the absolute differences of the four bytes, plus c
+static inline unsigned __builtin_amdgcn_sad_u8(unsigned a, unsigned b, unsigned c) {
+    for (int i = 0; i < 4; i++) {
+        int x = (int)((a >> (8 * i)) & 255u), y = (int)((b >> (8 * i)) & 255u);
+        c += (unsigned)(x > y ? x - y : y - x);
+    }
+    return c;
+}
 static inline unsigned __builtin_amdgcn_ubfe(unsigned s, unsigned off, unsigned w) {
     off &= 31; w &= 31;
     return w ? (s >> off) & ((1u << w) - 1) : 0;

@@ -65,6 +65,12 @@ typedef uint32_t u32;
 #define I_saveexec(r)    "s_and_saveexec_b64 s[10:11], exec\ns_cbranch_execz 1f\ns_nop 0\n1:\ns_or_b64 exec, exec, s[10:11]\n"
 #define I_ballot_br(r)   "v_cmp_ge_u32 s[10:11], " r ", " r "\ns_cmp_lg_u64 s[10:11], 0\ns_cbranch_scc1 1f\ns_nop 0\n1:\n"
 #define I_ballot_nobr(r) "v_cmp_ge_u32 s[10:11], " r ", " r "\ns_cmp_lg_u64 s[10:11], 0\ns_cbranch_scc0 1f\ns_nop 0\n1:\n"
+// a select on a comparison, three ways (3 instruction slots each).  cmpsel: v_cmp into vcc, the s_nop 1 that gfx950
+// requires before a VALU reads an SGPR a VALU wrote, v_cndmask; cmpsel_sgpr: the same through an SGPR pair;
+// arithsel: no mask register at all: the sign of a difference smeared over the word picks the operand (v_bitop3)
+#define I_cmpsel(r)      "v_cmp_lt_u32 vcc, " r ", %8\ns_nop 1\nv_cndmask_b32 " r ", " r ", %9, vcc\n"
+#define I_cmpsel_sgpr(r) "v_cmp_lt_u32 s[10:11], " r ", %8\ns_nop 1\nv_cndmask_b32 " r ", " r ", %9, s[10:11]\n"
+#define I_arithsel(r)    "v_sub_u32 v100, " r ", %8\nv_ashrrev_i32 v100, 31, v100\nv_bitop3_b32 " r ", " r ", %9, v100 bitop3:0xd8\n"
 // 64-bit forms (r = a VGPR pair)
 #define I_lshl64(r)     "v_lshlrev_b64 " r ", 1, " r "\n"
 #define I_lshl64v(r)    "v_lshlrev_b64 " r ", %8, " r "\n"
@@ -98,7 +104,7 @@ struct Rec { u64 cycles, real; u32 hw_id, xcc; };
             t0 = __builtin_amdgcn_s_memtime();                                                             \
             for (int it = 0; it < iters; it++)                                                             \
                 asm volatile(BODY : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6),  \
-                             "+v"(x7) : "v"(a), "v"(b) : "s10", "s11", "s12", "vcc", "scc");                      \
+                             "+v"(x7) : "v"(a), "v"(b) : "s10", "s11", "s12", "vcc", "scc", "v100");                      \
             t1 = __builtin_amdgcn_s_memtime();                                                             \
             r1 = __builtin_amdgcn_s_memrealtime();                                                         \
         }                                                                                                  \
@@ -117,7 +123,8 @@ struct Rec { u64 cycles, real; u32 hw_id, xcc; };
     X(and, 1) X(xor, 1) X(or3, 1) X(add, 1) X(add3, 1) X(lshr, 1) X(lshl_or, 1) X(mov, 1) X(bitop3, 1) X(bcnt, 1) X(bfe, 1) \
     X(min, 1) X(max, 1) X(mul_lo, 1) X(mul_hi, 1) X(mul_u24, 1) X(mad_u24, 1) X(cndmask, 1) X(cmp, 1) X(cmp_vcc, 1)          \
     X(readlane, 1) X(sdwa, 1) X(fma, 1) X(snop, 1) X(sand, 1) X(sadd, 1) X(select, 3)                                       \
-    X(br_taken, 2) X(br_not, 3) X(execz, 2) X(saveexec, 4) X(ballot_br, 3) X(ballot_nobr, 4)
+    X(br_taken, 2) X(br_not, 3) X(execz, 2) X(saveexec, 4) X(ballot_br, 3) X(ballot_nobr, 4)                          \
+    X(cmpsel, 3) X(cmpsel_sgpr, 3) X(arithsel, 3)
 #define OP64(X) X(lshl64, 1) X(lshl64v, 1) X(lshr64, 1) X(lshl_add64, 1) X(mov64, 1) X(mad64, 1)
 
 #define DEF32(n, k) KERNEL(k32_##n##_ind, u32, REP8(IND8(I_##n))) KERNEL(k32_##n##_dep, u32, REP8(DEP8(I_##n)))
