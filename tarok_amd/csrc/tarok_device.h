@@ -285,8 +285,10 @@ __device__ __forceinline__ u64 berac_scores(const Game &g) {
 // DEFER: a finished game's scores are NOT computed here (scores stays untouched): the caller keeps the
 // final state and calls final_scores() on it later (k_play scores the finished games of several tricks
 // together, on dense lanes).  want_tv = false skips the trick value (nobody asked for trick_info).
+// c_lead: where the caller kept the C plane of the moment the trick's first card was played (the trick-aligned
+// card loops), the trick's cards are the bits that plane has gained since; otherwise they come from the ids.
 template <bool TRUSTED = false, bool DEFER = false>
-__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info, bool want_tv = true) {
+__device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &trick_info, bool want_tv = true, const u64 *c_lead = nullptr) {
     if (!TRUSTED) {
         u64 legal = legal_now(g);
         bool ok = a < 54 && ((legal >> (a & 63)) & 1);
@@ -301,19 +303,27 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
     // higher card of the best card's suit, or as a tarok against a non-tarok — makes the winner the highest tarok
     // of the trick if one was played, else the highest card of the suit led (a card of any other suit never
     // becomes the best one): read off the trick's card mask instead of three dependent comparisons.
-    u32 c0 = g.trick & 63, c1 = (g.trick >> 6) & 63, c2 = (g.trick >> 12) & 63, c3 = (g.trick >> 18) & 63;
-    u64 tm = (1ULL << c0) | (1ULL << c1) | (1ULL << c2) | (1ULL << c3);
-    u32 th = TK_HI(tm), tl_ = TK_LO(tm) & (0xFFu << (c0 & 24));          // taroks played; cards of the suit led
-    // (the card led is a tarok or of its own suit: the chosen word is never zero; selects, no branches — a
-    // scalar branch costs a lone wave as much as a vector instruction)
-    u32 cw = (th ? 63u : 31u) - (u32)__builtin_clz(th ? th : tl_);
-    u32 w = c1 == cw ? 1u : (c2 == cw ? 2u : (c3 == cw ? 3u : 0u));
-    u32 ws = (g.leader + w) & 3;
+    u64 tm;
+    if (c_lead) tm = g.C ^ *c_lead;
+    else {
+        u32 c0 = g.trick & 63, c1 = (g.trick >> 6) & 63, c2 = (g.trick >> 12) & 63, c3 = (g.trick >> 18) & 63;
+        tm = (1ULL << c0) | (1ULL << c1) | (1ULL << c2) | (1ULL << c3);
+    }
+    u32 th = TK_HI(tm), tl_ = TK_LO(tm) & (0xFFu << (g.trick & 24));     // taroks played; cards of the suit led
+    // The winning card is the top bit of the tarok word, or of the suit word when no tarok was played (the card led
+    // is a tarok or of its own suit: the chosen word is never zero), and WHO played it is still written in the
+    // owner planes at that bit — played cards keep their player's seat bits until the trick changes hands just
+    // below.  Word masks, no compares, no selects (see legal_mask).
+    u32 zt = tk_zero_mask(th);
+    u32 wbit = 31u - (u32)__builtin_clz(TK_BITOP3(th, tl_, zt, (a_ & ~c_) | (b_ & c_)));
+    u32 aw = TK_BITOP3(TK_HI(g.A), TK_LO(g.A), zt, (a_ & ~c_) | (b_ & c_)), bw = TK_BITOP3(TK_HI(g.B), TK_LO(g.B), zt, (a_ & ~c_) | (b_ & c_));
+    u32 ws = __builtin_amdgcn_ubfe(aw, wbit, 1) | (__builtin_amdgcn_ubfe(bw, wbit, 1) << 1);
     {   // talon gift, Klop.py:67-71: talon.pop() joins the trick after the winner is known
-        bool gift = g.contract == TK_KLOP && g.tl > 0;
-        g.tl -= gift ? 1u : 0u;
+        u32 gift = tk_zero_mask(g.contract) & ((g.tl + 7u) >> 3);         // 1: a Klop with talon cards left
+        g.tl -= gift;
         u64 gb = 1ULL << ((u32)(g.talon >> (6 * g.tl)) & 63u);
-        tm |= gift ? gb : 0ULL;
+        u32 gm = 0u - gift;
+        tm |= TK_U64(TK_LO(gb) & gm, TK_HI(gb) & gm);
     }
     {   // the trick's cards change owner: plane bit := winner's seat bit where tm is set (one bitop3 per half)
         u32 m1 = (u32)((int)(ws << 31) >> 31), m2 = (u32)((int)(ws << 30) >> 31);

@@ -507,6 +507,7 @@ __device__ __forceinline__ void play_role(
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+    u64 c_lead = 0;
     // which of its two line buffers a lane could fill now (-> lacks: the next game's, lacks2: the one after it);
     // returns lacks.  `consumed >= 1`: before that, what the loads above could not take is not to be had.
     auto lines_lacking = [&](bool &lacks, bool &lacks2) __attribute__((always_inline)) {
@@ -569,7 +570,11 @@ __device__ __forceinline__ void play_role(
         const u32 pos = g.trick_no * 4 + g.nt;            // cards played so far in this game
         const u32 d_fin = g.declarer;
         const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, !STD && trick != nullptr) : apply_step<false, false>(g, a, scores, trick_info);
+        // (trick-aligned loops: the C plane as the trick's first card finds it — what it gains until the 4th card is the trick)
+        if constexpr (ALL && NT == 0) c_lead = g.C;
+        const u64 *lead_plane = (ALL && NT >= 0) ? &c_lead : nullptr;
+        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, !STD && trick != nullptr, lead_plane)
+                               : apply_step<false, false>(g, a, scores, trick_info, true, lead_plane);
         bool fin = res == 1;
         // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
         // write-only here; only the reference-layout observation (k_observe_ref) reads it
