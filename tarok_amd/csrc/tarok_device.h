@@ -204,7 +204,8 @@ __device__ __forceinline__ u64 obs_word_with(const Game &g, bool finished_now, u
     u64 o = legal;
     o |= (u64)((g.leader + g.nt) & 3) << 54;
     o |= (u64)(g.trick_no * 4 + g.nt) << 56;
-    if (finished_now || (!IN_PLAY && g.phase == TK_PHASE_DONE)) o |= 1ULL << 62;
+    if (IN_PLAY) o |= (u64)(finished_now ? 1u : 0u) << 62;               // (a shift of the caller's 0 / 1, no select)
+    else if (finished_now || g.phase == TK_PHASE_DONE) o |= 1ULL << 62;
     o |= (u64)g.error << 63;
     return o;
 }
@@ -340,13 +341,15 @@ __device__ __forceinline__ int apply_step(Game &g, u32 a, u64 &scores, u32 &tric
     g.leader = ws; g.nt = 0; g.trick = 0; g.trick_no++;
     // the game is over after twelve tricks, a Berac also the moment the declarer takes a trick (Berac.py:33-39);
     // straight-line selects: lanes of one wave sit in every combination of these cases
-    bool berac = ((0x280u >> g.contract) & 1u) != 0;                      // TK_BERAC = 7, TK_ODPRTI_BERAC = 9
-    bool over = g.trick_no >= 12 || (berac && ws == g.declarer);
+    // (as a 0 / 1 number made of plain vector instructions: the caller's test of it is then ONE compare, which a
+    // wave vote can use as it is; a vote on a compound condition goes compare -> scalar and -> select -> compare)
+    u32 berac01 = (0x280u >> g.contract) & 1u;                           // TK_BERAC = 7, TK_ODPRTI_BERAC = 9
+    u32 over01 = ((g.trick_no + 4u) >> 4) | (berac01 & tk_zero_mask(ws ^ g.declarer));      // (trick_no <= 12)
     if (!DEFER) {
-        if (over) scores = berac ? berac_scores(g) : score_game(g);
+        if (over01) scores = berac01 ? berac_scores(g) : score_game(g);
     }
-    g.phase = over ? (u32)TK_PHASE_DONE : g.phase;
-    return over ? 1 : 0;
+    g.phase |= over01;                                                   // TK_PHASE_PLAY (2) -> TK_PHASE_DONE (3)
+    return (int)over01;
 }
 
 // The scores of a game that apply_step has just finished, from its final state alone.

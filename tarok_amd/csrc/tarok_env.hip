@@ -508,6 +508,7 @@ __device__ __forceinline__ void play_role(
     // card c+1: computed once per card, carried in a register
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
     u64 c_lead = 0;
+    u64 pending = 0;                         // (wave uniform) lanes that came out of a swap without a line for their next game
     // which of its two line buffers a lane could fill now (-> lacks: the next game's, lacks2: the one after it);
     // returns lacks.  `consumed >= 1`: before that, what the loads above could not take is not to be had.
     auto lines_lacking = [&](bool &lacks, bool &lacks2) __attribute__((always_inline)) {
@@ -549,11 +550,17 @@ __device__ __forceinline__ void play_role(
         constexpr bool TOP_UP_EARLY = EARLY_LINES && ALL && NT == 0;
         constexpr bool TOP_UP_LATE = !(EARLY_LINES && ALL && NT == 3);
         if constexpr (TOP_UP_EARLY) {
-            bool lacks = false, lacks2 = false;
-            if (TK_RARE(__ballot(lines_lacking(lacks, lacks2)) != 0)) {
+            // (`pending`: set at a 4th card when a finishing lane came out of its swap without the next line —
+            // a scalar test here, not a vote on per-lane conditions at every trick.  Which lane holds which line
+            // is read off the tags: a lane holds the line of its next game if nep1 is that game's number.)
+            if (TK_RARE(pending != 0)) {
 #ifdef TK_EVENT_STAMPS
                 ev_early++;
 #endif
+                pending = 0;
+                bool base = spec && !blocked && consumed >= 1;
+                bool lacks = base && nep1 != cur_ep + 1 && consumed < allowed;
+                bool lacks2 = base && nep2 != cur_ep + 2 && consumed + 1 < allowed;
                 fetch_lines(lacks, lacks2);
             }
         }
@@ -579,8 +586,12 @@ __device__ __forceinline__ void play_role(
         // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
         // write-only here; only the reference-layout observation (k_observe_ref) reads it
         if (HIST && hist && play && res >= 0) hist[(int64_t)pos * n + i] = (uint8_t)a;
-        touched = touched || res != -2;
-        seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
+        // (trick-aligned loops: every lane plays whole tricks — both are set once, before the loop; a per-lane
+        // flag carried through a loop is a lane mask that costs three scalar instructions per update)
+        if constexpr (!(ALL && NT >= 0)) {
+            touched = touched || res != -2;
+            seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
+        }
         if (v) {
             if (RANDOM && (STD || action_out)) TK_STREAM_STORE(&action_out[row], (uint8_t)a);
             if (!STD && trick) TK_STREAM_STORE(&trick[row], (uint16_t)trick_info);
@@ -588,18 +599,91 @@ __device__ __forceinline__ void play_role(
         TK_SEG(0);
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
-        if constexpr (CAN_END && DEFER) {
+        // the trick-aligned loop of the one-wave-per-SIMD build: queue + renewal of the finishing lanes in one
+        // exec region, every per-lane fact kept in vector registers (below)
+        constexpr bool FAST_RENEW = EARLY_LINES && DEFER && ALL && NT == 3;
+        auto push_finished = [&](u64 fm, u32 slot0) __attribute__((always_inline)) {   // (lanes with fin; slot0: first free ring entry)
+            u32 e = (slot0 + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
+            fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
+            fq[4][e] = TK_LO(g.C); fq[5][e] = TK_HI(g.C); fq[6][e] = TK_LO(g.talon);
+            fq[7][e] = g.contract | (g.declarer << 4) | (g.king << 6) | (g.team << 8) | (g.tl << 12) | (g.trick_no << 16) |
+                       (g.leader << 20) | (TK_HI(g.talon) << 24);
+            fq[8][e] = ((u32)ci << 16) | tid;
+        };
+        auto swap_in = [&]() __attribute__((always_inline)) {                   // (lanes that hold their next game's line)
+            unpack_fresh(g, na.x, na.y, nb.x, nb.y);  // carries epar of the new game
+            key = nkey;
+            na = na2; nb = nb2; nkey = nkey2;
+            if constexpr (EARLY_LINES) nep1 = nep2;
+        };
+        // a game dealt here and now, for the lanes with deal_here (all 64 lanes must come along: deal_wave)
+        auto deal_in_place = [&](bool deal_here, Game &gd, u64 &kd) __attribute__((always_inline)) {
+            u64 pend = __ballot(deal_here);
+            if (TK_RARE(pend != 0)) {
+#ifdef TK_EVENT_STAMPS
+                ev_deal += (u32)__popcll(pend);
+#endif
+                u64 dkey = 0;
+                if (deal_here) dkey = game_key(seed, offset + (u64)i, cur_ep + 1);
+                u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+                u32 lane = __lane_id();
+                while (pend) {
+                    int l = __builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)dkey, l);
+                    u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(dkey >> 32), l);
+                    u64 w0, w1, w2, w3, wt;
+                    deal_wave(klo, khi, w0, w1, w2, w3, wt);
+                    if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+                }
+                if (deal_here) {
+                    u32 cc, d, k;
+                    sample_setup(dkey, mix, cc, d, k);
+                    setup_game(gd, h0, h1, h2, h3, tal, cc, d, k);
+                    gd.epar = TK_LINE(cur_ep + 1); gd.cprev = 0;
+                    if (gd.phase == TK_PHASE_EXCHANGE) bot_exchange(gd, dkey);
+                    kd = dkey;
+                }
+            }
+        };
+        if constexpr (FAST_RENEW) {
+            // Every lane is in play, so the lanes to renew are the finishing ones, and a lane can take its next game
+            // from the line it holds exactly when that line's tag is the game's number (a tag never matches a later
+            // game, and a line with the right tag IS the game: no "requested" / "dealt in place" flags here).  A
+            // finishing lane without its line is rare: its game is dealt on the spot INTO the line registers, so that
+            // there is one renewal path: queue entry, swap and counters of the finishing lanes in one exec region, all
+            // on vector registers.  (Per-lane flags kept as lane masks cost three scalar instructions per update
+            // inside a divergent region, and every compare -> mask -> select hop stalls a lone wave: tools/valu_issue.)
+            u64 fm = __ballot(fin);
+            if (TK_USUAL(fm != 0)) {                                      // (wave uniform)
+#ifdef TK_EVENT_STAMPS
+                ev_renew++;
+#endif
+                if (TK_RARE(fq_n >= 64)) drain_finished(64);              // room for 64 more: fewer than 64 wait now
+                const u32 slot0 = fq_head + fq_n;                         // (scalar bookkeeping outside the exec region)
+                fq_n += (u32)__popcll(fm);
+                // (a vote on ONE compare, and-ed with the finishing lanes as a scalar: see apply_step's last lines)
+                if (TK_RARE((fm & __ballot(nep1 != cur_ep + 1)) != 0)) {
+                    bool lineless = fin && nep1 != cur_ep + 1;
+                    // ran out of usable lines (the next ones are being re-dealt right now: the usual
+                    // bookkeeping stays valid) vs a line that should have been there and is not
+                    if (lineless && consumed < allowed) resync = true;
+                    if (lineless) blocked = true;                         // (no more fetches for this lane in this launch)
+                    Game d = g;
+                    u64 dk = key;
+                    deal_in_place(lineless, d, dk);
+                    if (lineless) { pack(d, na.x, na.y, nb.x, nb.y); nkey = dk; nep1 = cur_ep + 1; }
+                }
+                // (who comes out of the swap without the next line: what the swap moves up is the second buffer)
+                pending |= fm & __ballot(nep2 != cur_ep + 2);
+                if (fin) { push_finished(fm, slot0); swap_in(); cur_ep++; consumed++; }
+            }
+        }
+        if constexpr (CAN_END && DEFER && !FAST_RENEW) {
             u64 fm = __ballot(fin);
             if (TK_USUAL(fm != 0)) {                                      // (wave uniform)
                 if (TK_RARE(fq_n >= 64)) drain_finished(64);                       // room for 64 more: fewer than 64 wait now
-                if (fin) {
-                    u32 e = (fq_head + fq_n + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
-                    fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
-                    fq[4][e] = TK_LO(g.C); fq[5][e] = TK_HI(g.C); fq[6][e] = TK_LO(g.talon);
-                    fq[7][e] = g.contract | (g.declarer << 4) | (g.king << 6) | (g.team << 8) | (g.tl << 12) | (g.trick_no << 16) |
-                               (g.leader << 20) | (TK_HI(g.talon) << 24);
-                    fq[8][e] = ((u32)ci << 16) | tid;
-                }
+                if (fin) push_finished(fm, fq_head + fq_n);
                 fq_n += (u32)__popcll(fm);
             }
         }
@@ -620,7 +704,7 @@ __device__ __forceinline__ void play_role(
             acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
             acc_dirty = true;
         }
-        if (CAN_END && (ALL || autoreset)) {                 // (ALL implies auto-reset, and every lane was in play: done = just finished)
+        if (CAN_END && !FAST_RENEW && (ALL || autoreset)) {  // (ALL implies auto-reset, and every lane was in play: done = just finished)
             bool renew = ALL ? fin : (v && g.phase == TK_PHASE_DONE);
             if (TK_USUAL(__ballot(renew) != 0)) {
 #ifdef TK_EVENT_STAMPS
@@ -643,10 +727,7 @@ __device__ __forceinline__ void play_role(
                 }
                 bool swap = renew && !blocked && ok1 && (!EARLY_LINES || nep1 == cur_ep + 1);
                 if (swap) {
-                    unpack_fresh(g, na.x, na.y, nb.x, nb.y);  // carries epar of the new game
-                    key = nkey;
-                    na = na2; nb = nb2; nkey = nkey2;
-                    if constexpr (EARLY_LINES) nep1 = nep2;
+                    swap_in();
                     ok1 = ok2 && consumed + 1 < allowed;
                     ok2 = false;
                 }
@@ -655,33 +736,7 @@ __device__ __forceinline__ void play_role(
                 // bookkeeping stays valid) vs a line that should have been there and is not
                 if (deal_here && consumed < allowed) resync = true;
                 if (deal_here) blocked = true;
-                u64 pend = __ballot(deal_here);
-                if (TK_RARE(pend != 0)) {
-#ifdef TK_EVENT_STAMPS
-                    ev_deal += (u32)__popcll(pend);
-#endif
-                    u64 dkey = 0;
-                    if (deal_here) dkey = game_key(seed, offset + (u64)i, cur_ep + 1);
-                    u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
-                    u32 lane = __lane_id();
-                    while (pend) {
-                        int l = __builtin_ctzll(pend);
-                        pend &= pend - 1;
-                        u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)dkey, l);
-                        u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(dkey >> 32), l);
-                        u64 w0, w1, w2, w3, wt;
-                        deal_wave(klo, khi, w0, w1, w2, w3, wt);
-                        if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
-                    }
-                    if (deal_here) {
-                        u32 cc, d, k;
-                        sample_setup(dkey, mix, cc, d, k);
-                        setup_game(g, h0, h1, h2, h3, tal, cc, d, k);
-                        g.epar = TK_LINE(cur_ep + 1); g.cprev = 0;
-                        if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, dkey);
-                        key = dkey;
-                    }
-                }
+                deal_in_place(deal_here, g, key);
                 if (renew) { cur_ep++; consumed++; seats_dirty = true; }
             }
         }
@@ -689,8 +744,11 @@ __device__ __forceinline__ void play_role(
         // (ALL: a finished game has been replaced just above, so every lane is in play again)
         if (RANDOM) legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
         if (v) {
-            TK_STREAM_STORE(&obs[row], RANDOM ? obs_word_with<ALL>(g, fin, legal) : obs_word(g, fin));
-            if (STD || done) TK_STREAM_STORE(&done[row], (uint8_t)(fin ? 1 : 0));
+            // (ALL: res is 0 or 1 — the number itself goes into the observation's bit 62 and the done row, no selects)
+            const u32 fin01 = ALL ? (u32)res : (fin ? 1u : 0u);
+            TK_STREAM_STORE(&obs[row], RANDOM ? (obs_word_with<true>(g, false, legal) | ((u64)(ALL ? fin01 : ((fin || g.phase == TK_PHASE_DONE) ? 1u : 0u)) << 62))
+                                              : obs_word(g, fin));
+            if (STD || done) TK_STREAM_STORE(&done[row], (uint8_t)fin01);
         }
         TK_SEG(3);
     };
@@ -704,6 +762,7 @@ __device__ __forceinline__ void play_role(
     if (autoreset && __ballot(valid && g.phase == TK_PHASE_PLAY) == ~0ULL) {
         if ((cards & 3) == 0 && __ballot(g.nt != 0) == 0) {
             auto tricks = [&](auto std_tag) __attribute__((always_inline)) {
+                touched = true; seats_dirty = true;          // (cards >= 4: every lane plays a whole trick)
                 for (int c = 0; c < cards; c += 4) {
 #ifdef TK_CARD_STAMPS                       // diagnostics build (tools/card_probe.py): cycles of cards 0-2 vs the trick's 4th card
                     u64 ts_a = __builtin_amdgcn_s_memtime();
@@ -810,7 +869,7 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
     play_kernel_body<RANDOM, HIST, false>(TK_PLAY_FWD);
 }
 template <bool RANDOM, bool HIST>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_play_wide(TK_PLAY_ARGS) {
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
     play_kernel_body<RANDOM, HIST, true>(TK_PLAY_FWD);
 }
 
