@@ -33,9 +33,9 @@ Extra objects on the JSON line:
   roofline_step_api  the reset()/step()/legal_actions() surface an external policy drives
                      (tarok_policy_random + tarok_step, one card per launch), where 54 B/step
                      IS the right accounting.
-  issue_roofline     what really bounds k_play<true>: vector-instruction issue (instruction
-                     count per step from the committed SQ counters x the measured issue cost
-                     per instruction from tools/valu_issue.hip).
+  issue_roofline     what really bounds k_play<true>: instruction issue (the play role's
+                     instruction count per step from the committed SQ counters x the measured
+                     issue cost per instruction from tools/valu_issue.hip).
   cpu_baseline       the CPU oracle (oracle/, a C port of the reference rules — test
                      infrastructure, used here only as the reported baseline) on the host
                      cores, bounded sample of the same workload.  rank 0, N=1 only.
@@ -318,34 +318,44 @@ def main():
                         "DESIGN.md has the N sweep)" % (n, n * 520 / 1e6, (n + 63) // 64))
         out["roofline"] = roof
 
-        # ---- what actually bounds the kernel: instruction issue.  Instructions per step from
-        # the committed SQ counter passes of this command (tools/sq_counters.sh), issue costs from the
-        # microbenchmark (tools/valu_issue.hip -> profiles/<tag>_valu_issue.json): a wave that is alone on its
-        # SIMD issues one instruction of ANY kind per ~4.6 cycles; with two or more waves per SIMD the SIMD's
-        # own time per VALU instruction (full rate ~2.3, half rate ~4.2 cycles) is the limit.
+        # ---- what actually bounds the kernel: instruction issue.  A wave that is alone on its SIMD
+        # issues one instruction of ANY kind per ~4.6 cycles (tools/valu_issue.hip -> profiles/<tag>_valu_issue.json);
+        # at 65,536 games every SIMD holds one play wave, and the refill waves that share the SIMDs for part of the
+        # launch do not slow it (tools/first_launches.py: a launch without refill work has the same play-wave time).
+        # So the one-wave ceiling is priced on the PLAY role's instructions alone: SQ counters of launches whose
+        # refill workgroups have nothing to do (tools/play_only_counters.sh).  With two or more waves per SIMD the
+        # SIMD's own time per VALU instruction (full rate ~2.3, half rate ~4.2 cycles) over ALL instructions of a
+        # launch (tools/sq_counters.sh) is the limit.
         sq, sq_prov = load_profile("%s_sq_counters.json" % PROFILE_TAG, sha)
+        po, po_prov = load_profile("%s_play_only_counters.json" % PROFILE_TAG, sha)
         vi, vi_prov = load_profile("%s_valu_issue.json" % PROFILE_TAG, sha)
-        if sq and vi and sq.get("cards_per_launch") == cards and sq.get("games") == n and "SQ_INSTS_VALU" in sq:
-            wave_steps = sq["games"] / 64.0 * sq["cards_per_launch"]
-            valu = sq["SQ_INSTS_VALU"]["mean"] / wave_steps
-            every = sum(sq[k]["mean"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR",
-                                                "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH") if k in sq) / wave_steps
+        kinds = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH")
+        if sq and po and vi and all(p.get("cards_per_launch") == cards and p.get("games") == n and "SQ_INSTS_VALU" in p for p in (sq, po)):
+            wave_steps = n / 64.0 * cards
+            valu_all = sq["SQ_INSTS_VALU"]["mean"] / wave_steps
+            every_all = sum(sq[k]["mean"] for k in kinds if k in sq) / wave_steps
+            every_play = sum(po[k]["mean"] for k in kinds if k in po) / wave_steps
             clock = vi.get("clock_hz", 2.4e9)
-            simd_ceiling = 1024 * clock * 64.0 / (valu * vi["k_play_mix_cycles_per_valu"])
-            lone_ceiling = 1024 * clock * 64.0 / (every * vi["lone_wave_cycles_per_instruction"])
+            simd_ceiling = 1024 * clock * 64.0 / (valu_all * vi["k_play_mix_cycles_per_valu"])
+            lone_ceiling = 1024 * clock * 64.0 / (every_play * vi["lone_wave_cycles_per_instruction"])
             lone = (n + 63) // 64 <= 1024
             ceiling = lone_ceiling if lone else simd_ceiling
-            out["issue_roofline"] = {
+            iss = {
                 "bound": "instruction issue, one wave per SIMD" if lone else "SIMD time of the VALU instructions",
-                "valu_instructions_per_step": valu, "all_instructions_per_step": every,
+                "play_role_instructions_per_step": every_play, "all_roles_instructions_per_step": every_all,
+                "all_roles_valu_instructions_per_step": valu_all,
                 "lone_wave_cycles_per_instruction": vi["lone_wave_cycles_per_instruction"],
                 "simd_cycles_per_valu_instruction_k_play_mix": vi["k_play_mix_cycles_per_valu"], "clock_hz": clock,
                 "ceiling_one_wave_per_simd": lone_ceiling, "ceiling_simd_throughput": simd_ceiling,
                 "ceiling_steps_per_s_per_gpu": ceiling, "frac": value / world_size / ceiling,
-                "provenance": {"counters": sq_prov, "issue_costs": vi_prov},
-                "note": "instructions per step = SQ counters of a launch / (games / 64 x cards): the refill waves' deals are "
-                        "counted in, although they share SIMDs with the play waves only briefly, so the one-wave ceiling is an "
-                        "under-estimate; 1024 SIMDs x clock x 64 lanes / (instructions per step x cycles per instruction)"}
+                "provenance": {"counters_all_roles": sq_prov, "counters_play_role": po_prov, "issue_costs": vi_prov},
+                "note": "instructions per step = SQ counters of a launch / (games / 64 x cards); ceiling = 1024 SIMDs x clock x "
+                        "64 lanes / (instructions per step x cycles per instruction).  The play wave falls short of its one-wave "
+                        "ceiling by the stalls the microbenchmark prices: a select through a compare costs 16.6 cycles, on a "
+                        "compound condition 28.5, a taken branch ~25, a vote-and-branch ~50 (profiles/<tag>_valu_issue.json)"}
+            if "SQ_WAVE_CYCLES" in po and "SQ_WAIT_ANY" in po:
+                iss["play_role_wave_time_waiting_frac"] = po["SQ_WAIT_ANY"]["mean"] / po["SQ_WAVE_CYCLES"]["mean"]
+            out["issue_roofline"] = iss
 
     if not args.no_extras:
         # ---- side measurements (not `value`); lock-steps per region = the headline's, capped

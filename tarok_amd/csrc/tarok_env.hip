@@ -509,6 +509,8 @@ __device__ __forceinline__ void play_role(
     u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
     u64 c_lead = 0;
     u64 pending = 0;                         // (wave uniform) lanes that came out of a swap without a line for their next game
+    u32 blocked_v = 0, resync_v = 0;         // `blocked` / `resync` of the fast-renewal loop, as numbers (a bool carried through a loop is a
+                                             // lane mask, merged with three scalar instructions at every join, used or not)
     // which of its two line buffers a lane could fill now (-> lacks: the next game's, lacks2: the one after it);
     // returns lacks.  `consumed >= 1`: before that, what the loads above could not take is not to be had.
     auto lines_lacking = [&](bool &lacks, bool &lacks2) __attribute__((always_inline)) {
@@ -558,7 +560,7 @@ __device__ __forceinline__ void play_role(
                 ev_early++;
 #endif
                 pending = 0;
-                bool base = spec && !blocked && consumed >= 1;
+                bool base = spec && blocked_v == 0 && consumed >= 1;
                 bool lacks = base && nep1 != cur_ep + 1 && consumed < allowed;
                 bool lacks2 = base && nep2 != cur_ep + 2 && consumed + 1 < allowed;
                 fetch_lines(lacks, lacks2);
@@ -667,8 +669,8 @@ __device__ __forceinline__ void play_role(
                     bool lineless = fin && nep1 != cur_ep + 1;
                     // ran out of usable lines (the next ones are being re-dealt right now: the usual
                     // bookkeeping stays valid) vs a line that should have been there and is not
-                    if (lineless && consumed < allowed) resync = true;
-                    if (lineless) blocked = true;                         // (no more fetches for this lane in this launch)
+                    resync_v |= (lineless && consumed < allowed) ? 1u : 0u;
+                    blocked_v |= lineless ? 1u : 0u;                      // (no more fetches for this lane in this launch)
                     Game d = g;
                     u64 dk = key;
                     deal_in_place(lineless, d, dk);
@@ -797,7 +799,7 @@ __device__ __forceinline__ void play_role(
         int4 sa = make_int4(sacc[0][tid], sacc[1][tid], sacc[2][tid], sacc[3][tid]);
         if (sa.x | sa.y | sa.z | sa.w) { acc.x += sa.x; acc.y += sa.y; acc.z += sa.z; acc.w += sa.w; acc_dirty = true; }
     }
-    u32 np = resync ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
+    u32 np = (resync || resync_v != 0) ? (u32)TK_AHEAD : min(consumed, (u32)TK_AHEAD);
     if (valid) {
         g.cprev = np;                        // the next launch must not read those lines
         if (acc_dirty) cnt[i].score_sum = acc;

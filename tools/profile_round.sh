@@ -30,6 +30,9 @@ for N in 65536 1048576 4194304 16777216; do
 done
 bash tools/sq_counters.sh 65536 $TAG/sq64k > /dev/null 2>&1 && cp gpurun_out/$TAG/sq64k/sq_counters.json $OUT/sq_counters.json
 bash tools/sq_counters.sh 4194304 $TAG/sq4m > /dev/null 2>&1 && cp gpurun_out/$TAG/sq4m/sq_counters.json $OUT/sq_counters_4194304.json
+bash tools/play_only_counters.sh 65536 $TAG/play_only > /dev/null 2>&1 && cp gpurun_out/$TAG/play_only/play_only_counters.json $OUT/play_only_counters.json
+timeout -k 10 600 ./tools/valu_issue 1500 > $OUT/valu_issue_raw.json 2> $OUT/valu_issue.err
+python3 tools/first_launches.py 65536 $CARDS > $OUT/first_launches.txt 2>&1
 python3 tools/krog_stamps.py 65536 $CARDS > $OUT/wave_stamps_65536.txt 2>&1
 python3 tools/card_probe.py 65536 $CARDS > $OUT/card_probe_65536.txt 2>&1
 python3 tools/mlp_time.py 65536 > $OUT/policy_mlp_times.txt 2>&1

@@ -36,6 +36,7 @@ PRICED_AS = {
     "v_readlane_b32": "readlane", "v_readfirstlane_b32": "readlane", "v_lshlrev_b64": "lshl64v", "v_lshrrev_b64": "lshr64",
     "v_lshl_add_u64": "lshl_add64", "v_mov_b64": "mov64", "v_mad_u64_u32": "mad64", "v_addc_co_u32": "cndmask",
     "v_subb_co_u32": "cndmask", "v_ffbl_b32": "bcnt", "v_ffbh_u32": "bcnt", "v_lshrrev_b16": "sdwa", "v_lshlrev_b16": "sdwa",
+    "v_sad_u8": "add3", "v_mbcnt_lo_u32_b32": "bcnt", "v_mbcnt_hi_u32_b32": "bcnt", "v_subbrev_co_u32": "cndmask",
 }
 
 
@@ -46,7 +47,7 @@ def isa_mix():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                            "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     L = open(out).read().split("\n")
-    a = next(i for i, l in enumerate(L) if l.startswith("_Z6k_playILb1ELb0EE"))      # k_play<true, false>: the 128-VGPR build
+    a = next(i for i, l in enumerate(L) if l.startswith("_Z11k_play_wideILb1ELb0EE"))  # k_play_wide<true, false>: the build the Bot-policy launches use
     b = next(i for i in range(a, len(L)) if L[i].startswith(".Lfunc_end"))
     K = L[a:b]
     heads = [i for i, l in enumerate(K) if "Loop Header: Depth=1" in l and "Inner" not in l]
@@ -117,8 +118,16 @@ def main():
             "VOP3 such as v_or3/v_add3/v_lshl_or, SDWA forms, every 64-bit shift / move / add) ~%.1f" % (table["and"]["simd_cost"], half_cost),
             "a wave with 32 active lanes (low half or even lanes) issues no faster than a full one (half_waves): splitting "
             "the 65,536 games over twice as many half-filled waves buys no issue slots",
-            "dependent chains cost the same as independent ones at these rates (no exposed ALU latency)",
-        ],
+            "dependent chains of plain vector instructions cost the same as independent ones (no exposed ALU latency)",
+        ] + ([
+            "a per-lane select is where a lone wave loses time: through a compare (v_cmp, the two idle slots gfx950 wants before "
+            "a VALU reads a mask a VALU wrote, v_cndmask) %.1f cycles, on a compound condition (v_cmp, s_and, v_cndmask) %.1f, "
+            "as three plain vector instructions (difference, sign smear, v_bitop3) %.1f"
+            % (3 * table["cmpsel"]["lone_wave"], 3 * table["select"]["lone_wave"], 3 * table["arithsel"]["lone_wave"]),
+            "branches: s_cmp + taken branch %.1f cycles, s_cmp + branch not taken + the next instruction %.1f, and the "
+            "`if (__ballot(c))` shape (v_cmp into an SGPR pair, s_cmp_lg_u64, branch taken) %.1f for its three instructions"
+            % (2 * table["br_taken"]["lone_wave"], 3 * table["br_not"]["lone_wave"], 3 * table["ballot_br"]["lone_wave"]),
+        ] if all(k in table for k in ("cmpsel", "select", "arithsel", "br_taken", "br_not", "ballot_br")) else []),
         "ops": table,
         "half_waves": raw["half_waves"],
         "k_play_static_mix": {"valu_by_priced_row": priced, "valu_unpriced_counted_as_half_rate": unpriced, "non_valu": other,
