@@ -377,6 +377,11 @@ def main():
                                         "note": "wall time of the timed region / lock-steps: both launches and their gaps are "
                                                 "charged to the step; at %d games (state cache resident, one wave per SIMD) a "
                                                 "launch is latency bound — see profiles/ for the N sweep of this path" % n}
+            # measured HBM bytes of the two kernels of a lock-step (PMC passes of the all-modes command)
+            pma, pma_prov = load_profile("%s_pmc_fetch_write_all_modes_%d.json" % (PROFILE_TAG, n), sha)
+            if pma and "k_step_traffic_bytes_per_launch" in pma:
+                out["roofline_step_api"]["traffic"] = pma["k_step_traffic_bytes_per_launch"] + pma.get("k_policy_traffic_bytes_per_launch", 0)
+                out["roofline_step_api"]["traffic_provenance"] = pma_prov
         # (a') one trick per launch (tarok_krog_random, 4 cards)
         if cards != 4:
             p4, dt4 = leg(4, max(1, side_steps // 4))
