@@ -279,6 +279,27 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
         env.close()
 
 
+def test_long_launches_vs_oracle(T, O, S):
+    """The bench's launch length and beyond: 128 / 160 / 192 cards per launch (a slot finishes up to a dozen games
+    within one launch: early line top-ups, the fast renewal of the trick-aligned loop, finishing lanes WITHOUT a
+    line — dealt on the spot into the line registers — and, at 192, slots that run out of dealt-ahead lines), with
+    an extra prefetch after every launch and without (the lines then come from the refill workgroups alone), 16,384 games x 1,920 lock-steps vs the
+    oracle: episode numbers, score sums, canonical state, observation words."""
+    n, seed, steps = 16384, 5, 1920
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
+    for cards, chunk, pf in [(128, 640, 128), (128, 0, 0), (160, 960, 0), (192, 1920, 0), (64, 640, 64)]:
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+        env.reset()
+        env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
+        ep, ss = env.counters()
+        cfg = (cards, chunk, pf)
+        assert (ep == ref["episode"]).all(), cfg
+        assert (ss == ref["score_sum"]).all(), cfg
+        assert (env.state() == ref["lanes"]).all(), cfg
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), cfg
+        env.close()
+
+
 def test_krog_kernel_writes_what_four_single_steps_write(T, S):
     """tarok_krog_random(cards): row c of every output equals what the c-th tarok_step_random
     call writes (actions, observation words, done, per-trick info, scores), with and without
