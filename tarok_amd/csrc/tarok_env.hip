@@ -511,14 +511,7 @@ __device__ __forceinline__ void play_role(
     u64 pending = 0;                         // (wave uniform) lanes that came out of a swap without a line for their next game
     u32 blocked_v = 0, resync_v = 0;         // `blocked` / `resync` of the fast-renewal loop, as numbers (a bool carried through a loop is a
                                              // lane mask, merged with three scalar instructions at every join, used or not)
-    // which of its two line buffers a lane could fill now (-> lacks: the next game's, lacks2: the one after it);
-    // returns lacks.  `consumed >= 1`: before that, what the loads above could not take is not to be had.
-    auto lines_lacking = [&](bool &lacks, bool &lacks2) __attribute__((always_inline)) {
-        bool base = spec && !blocked && consumed >= 1;
-        lacks = base && !ok1 && consumed < allowed;
-        lacks2 = base && !ok2 && consumed + 1 < allowed;
-        return lacks;
-    };
+    // fill the line buffers of the lanes that lack them (lacks: the next game's, lacks2: the one after it)
     auto fetch_lines = [&](bool lacks, bool lacks2) __attribute__((always_inline)) {
         if (lacks) {
             const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
@@ -608,8 +601,14 @@ __device__ __forceinline__ void play_role(
             u32 e = (slot0 + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
             fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
             fq[4][e] = TK_LO(g.C); fq[5][e] = TK_HI(g.C); fq[6][e] = TK_LO(g.talon);
-            fq[7][e] = g.contract | (g.declarer << 4) | (g.king << 6) | (g.team << 8) | (g.tl << 12) | (g.trick_no << 16) |
-                       (g.leader << 20) | (TK_HI(g.talon) << 24);
+            // (one v_lshl_or per field: left alone the compiler builds a tree of shifts and v_or3, twelve instructions)
+            u32 m = (g.declarer << 4) | g.contract;      TK_KEEP_VGPR(m);
+            m = (g.king << 6) | m;                       TK_KEEP_VGPR(m);
+            m = (g.team << 8) | m;                       TK_KEEP_VGPR(m);
+            m = (g.tl << 12) | m;                        TK_KEEP_VGPR(m);
+            m = (g.trick_no << 16) | m;                  TK_KEEP_VGPR(m);
+            m = (g.leader << 20) | m;                    TK_KEEP_VGPR(m);
+            fq[7][e] = (TK_HI(g.talon) << 24) | m;
             fq[8][e] = ((u32)ci << 16) | tid;
         };
         auto swap_in = [&]() __attribute__((always_inline)) {                   // (lanes that hold their next game's line)
@@ -857,7 +856,7 @@ __device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
     else {
-#ifdef TK_PLAY_PRIO
+#ifdef TK_PLAY_PRIO                          // diagnostics build: wave priority of the play role (no effect: profiles/r02_ab_lone_wave_rewrite.txt)
         __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
 #endif
         play_role<RANDOM, HIST, WIDE>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
