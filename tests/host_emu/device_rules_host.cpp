@@ -45,7 +45,31 @@ static int replay(const char *in, const char *out) {
     return 0;
 }
 
+// direct checks of the branch-free helpers against the obvious loops
+static int self_check() {
+    const u32 edge[] = {0u, 1u, 0x80u, 0x8000u, 0x80000000u, 0xFF000000u, 0x7FFFFFFFu, 0xFFFFFFFFu, 0x01010101u};
+    for (u32 x : edge)
+        if (tk_zero_mask(x) != (x == 0 ? ~0u : 0u)) { fprintf(stderr, "tk_zero_mask(%08x)\n", x); return 6; }
+    u64 r = 0x9E3779B97F4A7C15ULL;
+    for (int it = 0; it < 200000; it++) {
+        r ^= r << 13; r ^= r >> 7; r ^= r << 17;
+        u64 m = r & TK_DECK;
+        if (it & 1) { u64 r2 = r * 0xD1B54A32D192ED03ULL; m &= r2 | (r2 >> 17); m &= (r2 >> 29) | (r2 << 11); }   // sparse, like a hand
+        if (it % 1000 == 0) m = TK_DECK;
+        if (it % 1000 == 1) m = 1ULL << (it % 54);
+        int k = 0;
+        for (u32 c = 0; c < 54; c++)
+            if ((m >> c) & 1) {
+                if (kth_bit(m, (u32)k) != c) { fprintf(stderr, "kth_bit(%016llx, %d)\n", (unsigned long long)m, k); return 7; }
+                k++;
+            }
+        if (tk_zero_mask((u32)m) != ((u32)m == 0 ? ~0u : 0u)) return 6;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (int rc = self_check()) return rc;
     if (argc == 4 && argv[1][0] == 'r') return replay(argv[2], argv[3]);
     if (argc < 7) { fprintf(stderr, "usage: %s seed offset n episode mix out.bin\n", argv[0]); return 2; }
     u64 seed = strtoull(argv[1], 0, 10), offset = strtoull(argv[2], 0, 10);
@@ -69,6 +93,21 @@ int main(int argc, char **argv) {
         uint8_t actions[48];
         int16_t played = 0;
         Game gd = g;                     // the same game through the deferred-scoring form the multi-card kernel uses
+        Game gl = g;                     // ... and through the trick-aligned loops' form: the trick's cards from the C plane's gain
+        u64 c_lead = 0;
+        {   // a line of the dealt-ahead buffer is unpacked as a fresh game: the same as the general unpack
+            Game fa, fb; u64 x0, x1, y0, y1;
+            Game src = g; src.epar = (u32)(i % 14);
+            pack(src, x0, x1, y0, y1);
+            unpack(fa, x0, x1, y0, y1); unpack_fresh(fb, x0, x1, y0, y1);
+            if (fa.A != fb.A || fa.B != fb.B || fa.C != fb.C || fa.talon != fb.talon || fa.trick != fb.trick || fa.nt != fb.nt ||
+                fa.leader != fb.leader || fa.trick_no != fb.trick_no || fa.phase != fb.phase || fa.contract != fb.contract ||
+                fa.declarer != fb.declarer || fa.king != fb.king || fa.team != fb.team || fa.tl != fb.tl || fa.error != fb.error ||
+                fa.epar != fb.epar || fa.cprev != fb.cprev) {
+                fprintf(stderr, "unpack_fresh differs at game %ld\n", i);
+                return 8;
+            }
+        }
         for (int t = 0; t < 48; t++) {
             bool live = g.phase == TK_PHASE_PLAY;
             masks[t] = 0; seats[t] = -1; actions[t] = 255;
@@ -78,10 +117,18 @@ int main(int argc, char **argv) {
                 seats[t] = (int8_t)((g.leader + g.nt) & 3);
                 u32 a = policy_action(key, (u32)t, m);
                 actions[t] = (uint8_t)a;
-                u32 ti, ti2 = 0;
+                u32 ti = 0, ti2 = 0;
                 u64 untouched = 0x1234;
                 int r1 = apply_step<true>(g, a, scores, ti);
                 int r2 = apply_step<true, true>(gd, a, untouched, ti2, false);
+                if (gl.nt == 0) c_lead = gl.C;
+                u64 sl = 0; u32 ti3 = 0;
+                int r3 = apply_step<true>(gl, a, sl, ti3, true, &c_lead);
+                if (r3 != r1 || ti3 != ti || gl.A != g.A || gl.B != g.B || gl.C != g.C || gl.tl != g.tl || gl.leader != g.leader ||
+                    gl.trick_no != g.trick_no || gl.phase != g.phase || (r1 == 1 && sl != scores)) {
+                    fprintf(stderr, "lead-plane form differs at game %ld card %d\n", i, t);
+                    return 9;
+                }
                 if (r1 != r2 || untouched != 0x1234 || ti2 != 0 || gd.phase != g.phase || (r1 == 1 && final_scores(gd) != scores)) {
                     fprintf(stderr, "deferred scoring differs at game %ld card %d\n", i, t);
                     return 5;
