@@ -155,11 +155,34 @@ def rollout(seed, gidx0, n, episode, mix, threads=1, trace=True):
     return out
 
 
-def run_autoreset(seed, gidx0, n, mix, n_steps, episode0=0):
-    """CPU statement of tarok_run_random(..., TAROK_AUTO_RESET)."""
-    out = dict(episode=np.zeros(n, np.uint32), score_sum=np.zeros((n, 4), np.int32),
-               lanes=np.zeros((10, n), np.uint64), obs=np.zeros(n, np.uint64))
-    total = lib().to_run_autoreset(seed, gidx0, n, mix, episode0, n_steps, out["episode"].ctypes.data,
-                                   out["score_sum"].ctypes.data, out["lanes"].ctypes.data, out["obs"].ctypes.data)
-    out["total_steps"] = int(total)
-    return out
+def run_autoreset(seed, gidx0, n, mix, n_steps, episode0=0, threads=1):
+    """CPU statement of tarok_run_random(..., TAROK_AUTO_RESET).  threads > 1: the slots are split into
+    contiguous ranges run in parallel (slots are independent; the C call releases the GIL)."""
+    L = lib()
+
+    def part(lo, hi):
+        m = hi - lo
+        o = dict(episode=np.zeros(m, np.uint32), score_sum=np.zeros((m, 4), np.int32),
+                 lanes=np.zeros((10, m), np.uint64), obs=np.zeros(m, np.uint64))
+        o["total_steps"] = int(L.to_run_autoreset(seed, gidx0 + lo, m, mix, episode0, n_steps, o["episode"].ctypes.data,
+                                                  o["score_sum"].ctypes.data, o["lanes"].ctypes.data, o["obs"].ctypes.data))
+        return o
+    threads = max(1, min(int(threads), n))
+    if threads == 1:
+        return part(0, n)
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [n * k // threads for k in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(lambda k: part(cuts[k], cuts[k + 1]), range(threads)))
+    return dict(episode=np.concatenate([q["episode"] for q in parts]), score_sum=np.concatenate([q["score_sum"] for q in parts]),
+                lanes=np.concatenate([q["lanes"] for q in parts], axis=1), obs=np.concatenate([q["obs"] for q in parts]),
+                total_steps=sum(q["total_steps"] for q in parts))
+
+
+def policy_action(key, step, legal):
+    """The Bot policy's card (oracle/tarok_spec.py: uniform among the legal cards on draw 128 + step)."""
+    return int(lib().to_policy_action(int(key), int(step), int(legal)))
+
+
+def game_key(seed, gidx, episode):
+    return int(lib().to_game_key(int(seed), int(gidx), int(episode)))

@@ -16,7 +16,7 @@ ARCH = "gfx950"
 
 SYMBOLS = [
     "tarok_strerror", "tarok_abi_version", "tarok_device_count", "tarok_last_hip_error",
-    "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_reset", "tarok_exchange",
+    "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_set_option", "tarok_reset", "tarok_exchange",
     "tarok_legal_actions", "tarok_step", "tarok_prefetch", "tarok_policy_random", "tarok_step_random",
     "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy", "tarok_policy_mlp", "tarok_policy_step", "tarok_expand_features", "tarok_ppo_loss",
     "tarok_observe_ref", "tarok_observe_exchange_ref", "tarok_observe_hands_ref", "tarok_get_history", "tarok_set_history",
@@ -113,6 +113,8 @@ def lib():
     L.tarok_create.restype = i32; L.tarok_create.argtypes = [C.POINTER(vp), i32, i64, u64, u64, i32, i32]
     L.tarok_destroy.restype = None; L.tarok_destroy.argtypes = [vp]
     L.tarok_num_games.restype = i64; L.tarok_num_games.argtypes = [vp]
+    if hasattr(L, "tarok_set_option"):      # (absent from older libraries loaded through TAROK_LIB for A/B runs)
+        L.tarok_set_option.restype = i32; L.tarok_set_option.argtypes = [vp, i32, i32]
     L.tarok_reset.restype = i32; L.tarok_reset.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.tarok_exchange.restype = i32; L.tarok_exchange.argtypes = [vp, vp, vp, vp]
     L.tarok_legal_actions.restype = i32; L.tarok_legal_actions.argtypes = [vp, vp, vp, vp]

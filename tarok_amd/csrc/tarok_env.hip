@@ -3,8 +3,9 @@
 // One thread per game, 256-thread workgroups (4 waves).  Per-game state is the
 // 4 packed uint64 lanes of tarok_device.h, stored as two 16-byte SoA arrays
 // (s01[g] = play pair {X0,X1}, s23[g] = seat pair {Y0,Y1}): every wave-level
-// load/store moves 1 KiB contiguous.  The work is integer mask algebra + popcounts bounded by
-// HBM bandwidth (no MFMA).
+// load/store moves 1 KiB contiguous.  The work is integer mask algebra + popcounts (no MFMA): the
+// one-card step (k_step: the state through HBM on every card) is bounded by HBM bandwidth once the batch
+// streams, the multi-card Bot-policy kernel (k_play_wide: the state stays in registers) by instruction issue.
 //
 // Finished games are replaced at once (auto-reset) without a deal on the step's critical path:
 // every slot keeps its next FOURTEEN games ready in the lines of its Aux record (episode e lives in
@@ -55,12 +56,10 @@
 #endif
 // s_waitcnt vmcnt(0) (gfx9 encoding: expcnt and lgkmcnt left at their maxima)
 #define TK_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
-// wave-uniform branches of the card loop (play_role; EARLY_LINES = its one-wave-per-SIMD build): a taken branch
-// costs a lone wave ~25 cycles, one that falls through ~7 (tools/valu_issue: br_taken / br_not) — the usual path
-// is laid out as the fall-through.  Not in the 128-VGPR build: four waves hide a branch, and the block order
-// the hints give it puts spills into the scoring drain (4 M games: -12 %).
-#define TK_RARE(c) (EARLY_LINES ? __builtin_expect(!!(c), 0) : !!(c))
-#define TK_USUAL(c) (EARLY_LINES ? __builtin_expect(!!(c), 1) : !!(c))
+// wave-uniform branches of the card loop (play_role): a taken branch costs a lone wave ~25 cycles, one that falls
+// through ~7 (tools/valu_issue: br_taken / br_not) — the usual path is laid out as the fall-through.
+#define TK_RARE(c) __builtin_expect(!!(c), 0)
+#define TK_USUAL(c) __builtin_expect(!!(c), 1)
 
 // Per-slot side record: TK_AHEAD (fourteen) 64-byte next-game lines.  Line b holds the dealt-ahead
 // game whose episode number is b mod TK_AHEAD: its packed pairs, its RNG key and the episode number
@@ -108,7 +107,7 @@ struct tarok_env {
     u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
-    bool wide_regs;          // the no-spill build of the Bot-policy kernel (k_play_wide)
+    bool spec_loads;         // one-card step: finish-path loads issued speculatively next to the state load (step_role)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -317,11 +316,11 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {          // call af
     if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), 2u * launch_shard_size() - 1u);
 }
 
-// THE step kernel.  One launch plays `cards` cards of every game:
-//   RANDOM = false, cards = 1: tarok_step — the card comes from `action_in` (an external policy);
-//   RANDOM = true:  the Bot policy (Igralec.py:158-159) is evaluated in-kernel; cards = 1 is
-//                   tarok_step_random, cards = 4 one whole trick = one pass of the reference's krog
-//                   generator (Klop.py:47-79, Navadna_igra.py:115-141).
+// The step kernels.  One launch plays `cards` cards of every game:
+//   k_step (step_role), cards = 1: tarok_step — the card comes from `action_in` (an external policy) — and
+//                   tarok_step_random (the Bot policy, Igralec.py:158-159, evaluated in-kernel);
+//   k_play_wide (play_role), cards >= 2, Bot policy in-kernel: cards = 4 is one whole trick = one pass of the
+//                   reference's krog generator (Klop.py:47-79, Navadna_igra.py:115-141).
 // The packed state is read once, stays in registers while the cards are played and is written
 // once; everything a consumer of the trajectory needs is written for EVERY card: row c of
 // action/obs/done/trick/reward (rows `stride` games apart) belongs to the c-th card of the launch.
@@ -367,24 +366,15 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     }
 }
 
-// LDS of the deferred scoring (play_role): allocated only in the kernels that use it
-template <bool D> __device__ __forceinline__ u32 (*finq_storage())[9][TK_FINQ] {
-    if constexpr (D) { __shared__ u32 q[TK_BLOCK / 64][9][TK_FINQ]; return q; } else return nullptr;
-}
-template <bool D> __device__ __forceinline__ int (*sacc_storage())[TK_BLOCK] {
-    if constexpr (D) { __shared__ int a[4][TK_BLOCK]; return a; } else return nullptr;
-}
-
-// Play role of a step launch for the 256 slots of play workgroup `group`: thread `tid` (0..255)
-// plays slot group * 256 + tid; threads with active = false (a larger workgroup's extra threads)
-// only take part in the two barriers.  The card comes from action_in, or (action_in == NULL) from
-// a_reg, or with RANDOM from the in-kernel Bot policy.  EARLY_LINES: where the trick-aligned loops fetch the
-// lines of a lane's third and later games of a launch (see TOP_UP_EARLY below).
-template <bool RANDOM, bool HIST, bool EARLY_LINES = false>
+// Play role of a Bot-policy launch (tarok_krog_random: `cards` cards per launch, the card from the in-kernel Bot
+// policy, Igralec.py:158-159) for the 256 slots of play workgroup `group`: thread `tid` (0..255) plays slot
+// group * 256 + tid.  (One card per launch from an external policy: step_role below.)
+// HIST: also record the play history (one byte per card; tarok_create flag TAROK_HISTORY).
+template <bool HIST>
 __device__ __forceinline__ void play_role(
-    u32 group, u32 tid, bool active, u32 a_reg,
+    u32 group, u32 tid,
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 count, u32 *epoch,
-    const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
+    uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
@@ -397,18 +387,17 @@ __device__ __forceinline__ void play_role(
     // lanes active: a third of a play wave's time at 65,536 games (tools/card_probe.py).  Whenever 64 entries
     // wait they are scored in ONE pass on full lanes (drain_finished); the rest at the end of the launch.  The
     // scores go to their reward row from there and are summed per slot in LDS (sacc) for the slot's score_sum.
-    constexpr bool DEFER = RANDOM;
-    u32 (*finq)[9][TK_FINQ] = finq_storage<DEFER>();
-    int (*sacc)[TK_BLOCK] = sacc_storage<DEFER>();
+    __shared__ u32 finq[TK_BLOCK / 64][9][TK_FINQ];
+    __shared__ int sacc[4][TK_BLOCK];
     if (tid == 0) push_count = 0;
-    if constexpr (DEFER) { sacc[0][tid] = 0; sacc[1][tid] = 0; sacc[2][tid] = 0; sacc[3][tid] = 0; }
+    sacc[0][tid] = 0; sacc[1][tid] = 0; sacc[2][tid] = 0; sacc[3][tid] = 0;
     __syncthreads();
     u32 fq_head = 0, fq_n = 0;               // this wave's ring: first waiting entry, entries waiting (wave uniform)
-    u32 (*fq)[TK_FINQ] = DEFER ? finq[tid >> 6] : nullptr;
+    u32 (*fq)[TK_FINQ] = finq[tid >> 6];
     // score `cnt_` waiting entries (at most 64) of the wave's ring on dense lanes
     auto drain_finished = [&](u32 cnt_) __attribute__((always_inline)) {
         u32 lane = tid & 63;
-        if (DEFER && lane < cnt_) {
+        if (lane < cnt_) {
             u32 e = (fq_head + lane) & (TK_FINQ - 1);
             Game f;
             f.A = TK_U64(fq[0][e], fq[1][e]); f.B = TK_U64(fq[2][e], fq[3][e]); f.C = TK_U64(fq[4][e], fq[5][e]);
@@ -438,13 +427,11 @@ __device__ __forceinline__ void play_role(
     u64 t_real0 = 0, t_cyc0 = 0, t_play = 0;
     if (stamps) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_cyc0 = __builtin_amdgcn_s_memtime(); }
     int64_t i = (int64_t)group * TK_BLOCK + tid;
-    bool valid = active && i < n;
+    bool valid = i < n;
     int64_t ic = valid ? i : n - 1;
     Game g;
     load_game(g, s01, s23, ic);
-    u64 key = 0;
-    u32 a_in = 255;
-    if (RANDOM) key = gkey[ic]; else a_in = action_in ? action_in[ic] : a_reg;
+    u64 key = gkey[ic];
     bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
     // Lanes that can reach the end of their game within this launch (a game only ends on the 4th
     // card of a trick: Berac on any trick, the others in trick 12) issue their finish-path loads
@@ -460,35 +447,33 @@ __device__ __forceinline__ void play_role(
     int4 acc = make_int4(0, 0, 0, 0);
     u32 cur_ep = 0;
     // (na, nb, nkey, nep1): the line of the next game (episode cur_ep + 1), (na2, nb2, nkey2, nep2): of the
-    // one after it.  ok1 / ok2: the line is usable.  EARLY_LINES: ... has been requested (and was one this
-    // launch may take); its episode tag is compared when it is taken, so that nothing waits for the load
-    // where it is issued (line_tag).  Both are loaded here, before the loop, and topped up at the first
-    // card of a trick (below) — never across the loop's back edge: a load in flight there would make every
-    // iteration wait for the previous iteration's stores (vmcnt counts both, in order)
+    // one after it.  ok1 / ok2: the line has been requested (and was one this launch may take); its episode tag
+    // is compared when it is taken, so that nothing waits for the load where it is issued (line_tag).  Both
+    // are loaded here, before the loop, and topped up at the first card of a trick (below) — never across the
+    // loop's back edge: a load in flight there would make every iteration wait for the previous iteration's
+    // stores (vmcnt counts both, in order)
     ulonglong2 na = make_ulonglong2(0, 0), nb = na, na2 = na, nb2 = na;
     u64 nkey = 0, nkey2 = 0;
     u32 nep1 = 0, nep2 = 0;
     bool ok1 = false, ok2 = false;
-    auto line_tag = [&](bool &ok, u32 &nep, u32 tag, u32 want) __attribute__((always_inline)) {
-        if constexpr (EARLY_LINES) { nep = tag; ok = true; } else ok = tag == want;
-    };
+    auto line_tag = [&](bool &ok, u32 &nep, u32 tag) __attribute__((always_inline)) { nep = tag; ok = true; };
     if (spec) {
         acc = cnt[i].score_sum;
         cur_ep = cnt[i].episode;
         if (autoreset && allowed > 0) {
             const AuxLine *ln = &aux[i].line[TK_LINE(g.epar + 1)];
             na = ln->n01; nb = ln->n23; nkey = ln->nkey;
-            line_tag(ok1, nep1, ln->nep, cur_ep + 1);
+            line_tag(ok1, nep1, ln->nep);
             if (allowed > 1 && cards > 4) {          // a Berac can be over after 4 cards
                 const AuxLine *l2 = &aux[i].line[TK_LINE(g.epar + 2)];
                 na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
-                line_tag(ok2, nep2, l2->nep, cur_ep + 2);
+                line_tag(ok2, nep2, l2->nep);
             }
         }
     }
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
     u32 par = launch_parity(count);         // (`count` was requested before the state: it has arrived with it)
-    if (epoch) launch_counted(epoch);
+    launch_counted(epoch);
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
 #ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
@@ -506,7 +491,7 @@ __device__ __forceinline__ void play_role(
     bool acc_dirty = false, seats_dirty = false, touched = false;
     // the legal mask written into the observation after card c is the one the policy needs for
     // card c+1: computed once per card, carried in a register
-    u64 legal = (RANDOM && valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
+    u64 legal = (valid && g.phase == TK_PHASE_PLAY) ? legal_now(g) : 0;
     u64 c_lead = 0;
     u64 pending = 0;                         // (wave uniform) lanes that came out of a swap without a line for their next game
     u32 blocked_v = 0, resync_v = 0;         // `blocked` / `resync` of the fast-renewal loop, as numbers (a bool carried through a loop is a
@@ -516,12 +501,12 @@ __device__ __forceinline__ void play_role(
         if (lacks) {
             const AuxLine *ln = &aux[i].line[TK_LINE(cur_ep + 1)];
             na = ln->n01; nb = ln->n23; nkey = ln->nkey;
-            line_tag(ok1, nep1, ln->nep, cur_ep + 1);
+            line_tag(ok1, nep1, ln->nep);
         }
         if (lacks2) {
             const AuxLine *l2 = &aux[i].line[TK_LINE(cur_ep + 2)];
             na2 = l2->n01; nb2 = l2->n23; nkey2 = l2->nkey;
-            line_tag(ok2, nep2, l2->nep, cur_ep + 2);
+            line_tag(ok2, nep2, l2->nep);
         }
     };
     auto play_card = [&](auto all_tag, auto nt_tag, auto std_tag, int64_t row, int ci) __attribute__((always_inline)) {
@@ -535,15 +520,15 @@ __device__ __forceinline__ void play_role(
         constexpr int NT = decltype(nt_tag)::value;
         constexpr bool STD = decltype(std_tag)::value;
         if constexpr (NT >= 0) g.nt = (u32)NT;
-        // EARLY_LINES (the one-wave-per-SIMD build), trick-aligned loops: the lines of the next games are topped
+        // Trick-aligned loops: the lines of the next games are topped
         // up HERE, at the first card of a trick, as soon as one lane has used its two up — three cards (~1,400
         // cycles) before a game can end and take one: the memory round trip hides behind the rules, and the
         // compiler's wait at the first use counts past the stores issued since.  (A lane's `consumed` only moves
         // at a 4th card, so a lane that still lacks a line at the 4th card could not have fetched one: no fetch
         // on the spot in these loops.)  With four waves on a SIMD the other waves hide the round trip of a
         // fetch on the spot, and the earlier, more frequent top-ups only cost instructions (4 M games: -11 %).
-        constexpr bool TOP_UP_EARLY = EARLY_LINES && ALL && NT == 0;
-        constexpr bool TOP_UP_LATE = !(EARLY_LINES && ALL && NT == 3);
+        constexpr bool TOP_UP_EARLY = ALL && NT == 0;
+        constexpr bool TOP_UP_LATE = !(ALL && NT == 3);
         if constexpr (TOP_UP_EARLY) {
             // (`pending`: set at a 4th card when a finishing lane came out of its swap without the next line —
             // a scalar test here, not a vote on per-lane conditions at every trick.  Which lane holds which line
@@ -564,19 +549,15 @@ __device__ __forceinline__ void play_role(
 #ifdef TK_CARD_STAMPS
         if constexpr (ALL && NT == 3) cs_t = __builtin_amdgcn_s_memtime();
 #endif
-        u32 a = a_in;
-        if (RANDOM) a = play ? policy_action(key, g.trick_no * 4 + g.nt, legal) : 255u;
+        u32 a = play ? policy_action(key, g.trick_no * 4 + g.nt, legal) : 255u;
         u64 scores = 0;
         u32 trick_info = 0;
         int res = -2;
         const u32 pos = g.trick_no * 4 + g.nt;            // cards played so far in this game
-        const u32 d_fin = g.declarer;
-        const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
         // (trick-aligned loops: the C plane as the trick's first card finds it — what it gains until the 4th card is the trick)
         if constexpr (ALL && NT == 0) c_lead = g.C;
         const u64 *lead_plane = (ALL && NT >= 0) ? &c_lead : nullptr;
-        if (play) res = RANDOM ? apply_step<true, true>(g, a, scores, trick_info, !STD && trick != nullptr, lead_plane)
-                               : apply_step<false, false>(g, a, scores, trick_info, true, lead_plane);
+        if (play) res = apply_step<true, true>(g, a, scores, trick_info, !STD && trick != nullptr, lead_plane);
         bool fin = res == 1;
         // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): card `pos` of the game, one byte,
         // write-only here; only the reference-layout observation (k_observe_ref) reads it
@@ -588,15 +569,15 @@ __device__ __forceinline__ void play_role(
             seats_dirty = seats_dirty || (res >= 0 && g.nt == 0);
         }
         if (v) {
-            if (RANDOM && (STD || action_out)) TK_STREAM_STORE(&action_out[row], (uint8_t)a);
+            if (STD || action_out) TK_STREAM_STORE(&action_out[row], (uint8_t)a);
             if (!STD && trick) TK_STREAM_STORE(&trick[row], (uint16_t)trick_info);
         }
         TK_SEG(0);
         // (cards 0..2 of a trick cannot end a game: no finish / renewal code in their copies)
         constexpr bool CAN_END = !(ALL && NT >= 0 && NT < 3);
-        // the trick-aligned loop of the one-wave-per-SIMD build: queue + renewal of the finishing lanes in one
-        // exec region, every per-lane fact kept in vector registers (below)
-        constexpr bool FAST_RENEW = EARLY_LINES && DEFER && ALL && NT == 3;
+        // the trick-aligned loop: queue + renewal of the finishing lanes in one exec region, every per-lane fact
+        // kept in vector registers (below)
+        constexpr bool FAST_RENEW = ALL && NT == 3;
         auto push_finished = [&](u64 fm, u32 slot0) __attribute__((always_inline)) {   // (lanes with fin; slot0: first free ring entry)
             u32 e = (slot0 + __builtin_amdgcn_mbcnt_hi((u32)(fm >> 32), __builtin_amdgcn_mbcnt_lo((u32)fm, 0))) & (TK_FINQ - 1);
             fq[0][e] = TK_LO(g.A); fq[1][e] = TK_HI(g.A); fq[2][e] = TK_LO(g.B); fq[3][e] = TK_HI(g.B);
@@ -615,7 +596,7 @@ __device__ __forceinline__ void play_role(
             unpack_fresh(g, na.x, na.y, nb.x, nb.y);  // carries epar of the new game
             key = nkey;
             na = na2; nb = nb2; nkey = nkey2;
-            if constexpr (EARLY_LINES) nep1 = nep2;
+            nep1 = nep2;
         };
         // a game dealt here and now, for the lanes with deal_here (all 64 lanes must come along: deal_wave)
         auto deal_in_place = [&](bool deal_here, Game &gd, u64 &kd) __attribute__((always_inline)) {
@@ -680,7 +661,7 @@ __device__ __forceinline__ void play_role(
                 if (fin) { push_finished(fm, slot0); swap_in(); cur_ep++; consumed++; }
             }
         }
-        if constexpr (CAN_END && DEFER && !FAST_RENEW) {
+        if constexpr (CAN_END && !FAST_RENEW) {
             u64 fm = __ballot(fin);
             if (TK_USUAL(fm != 0)) {                                      // (wave uniform)
                 if (TK_RARE(fq_n >= 64)) drain_finished(64);                       // room for 64 more: fewer than 64 wait now
@@ -689,22 +670,6 @@ __device__ __forceinline__ void play_role(
             }
         }
         TK_SEG(1);
-        if (CAN_END && !DEFER && fin) {
-            if (reward) {
-                u64 rs = scores;
-                if ((flags & TAROK_REWARD_REF) && berac_fin) {
-                    // what rezultat_igre folds into a Berac defender's last transition (Igralec.py:434-437):
-                    // -20 when the hands are empty at the end (all twelve tricks were played), else +20
-                    int dv = g.trick_no >= 12 ? -20 : 20;
-                    rs = pack_scores(d_fin == 0 ? (int)(int16_t)(scores & 0xFFFF) : dv, d_fin == 1 ? (int)(int16_t)((scores >> 16) & 0xFFFF) : dv,
-                                     d_fin == 2 ? (int)(int16_t)((scores >> 32) & 0xFFFF) : dv, d_fin == 3 ? (int)(int16_t)(scores >> 48) : dv);
-                }
-                reinterpret_cast<u64 *>(reward)[row] = rs;
-            }
-            acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
-            acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
-            acc_dirty = true;
-        }
         if (CAN_END && !FAST_RENEW && (ALL || autoreset)) {  // (ALL implies auto-reset, and every lane was in play: done = just finished)
             bool renew = ALL ? fin : (v && g.phase == TK_PHASE_DONE);
             if (TK_USUAL(__ballot(renew) != 0)) {
@@ -726,7 +691,7 @@ __device__ __forceinline__ void play_role(
                         TK_WAIT_LOADS();
                     }
                 }
-                bool swap = renew && !blocked && ok1 && (!EARLY_LINES || nep1 == cur_ep + 1);
+                bool swap = renew && !blocked && ok1 && nep1 == cur_ep + 1;
                 if (swap) {
                     swap_in();
                     ok1 = ok2 && consumed + 1 < allowed;
@@ -743,12 +708,11 @@ __device__ __forceinline__ void play_role(
         }
         TK_SEG(2);
         // (ALL: a finished game has been replaced just above, so every lane is in play again)
-        if (RANDOM) legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
+        legal = (ALL || (v && g.phase == TK_PHASE_PLAY)) ? legal_now(g) : 0;
         if (v) {
             // (ALL: res is 0 or 1 — the number itself goes into the observation's bit 62 and the done row, no selects)
             const u32 fin01 = ALL ? (u32)res : (fin ? 1u : 0u);
-            TK_STREAM_STORE(&obs[row], RANDOM ? (obs_word_with<true>(g, false, legal) | ((u64)(ALL ? fin01 : ((fin || g.phase == TK_PHASE_DONE) ? 1u : 0u)) << 62))
-                                              : obs_word(g, fin));
+            TK_STREAM_STORE(&obs[row], obs_word_with<true>(g, false, legal) | ((u64)(ALL ? fin01 : ((fin || g.phase == TK_PHASE_DONE) ? 1u : 0u)) << 62));
             if (STD || done) TK_STREAM_STORE(&done[row], (uint8_t)fin01);
         }
         TK_SEG(3);
@@ -781,7 +745,7 @@ __device__ __forceinline__ void play_role(
 #endif
                 }
             };
-            if (RANDOM && action_out && done && !trick) tricks(std::true_type{});
+            if (action_out && done && !trick) tricks(std::true_type{});
             else tricks(std::false_type{});
         } else {
             for (int c = 0; c < cards; c++, row += stride) play_card(std::true_type{}, nt_any{}, std::false_type{}, row, c);
@@ -792,9 +756,9 @@ __device__ __forceinline__ void play_role(
     // ---- schedule the refills: after consuming, the slot must again hold episodes cur+1 .. cur+TK_AHEAD.
     // Each swap-in vacated one line (the others stay valid): the last np episodes are new;
     // a game dealt in place: all of them.
-    if constexpr (DEFER) {
-        while (fq_n) drain_finished(min(fq_n, 64u));                      // (at most two passes: fewer than 128 wait)
-        __builtin_amdgcn_s_waitcnt(0xC07F);                               // the wave's LDS adds have landed (lgkmcnt(0))
+    while (fq_n) drain_finished(min(fq_n, 64u));                          // (at most two passes: fewer than 128 wait)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   // the wave's LDS adds have landed (lgkmcnt(0))
+    {
         int4 sa = make_int4(sacc[0][tid], sacc[1][tid], sacc[2][tid], sacc[3][tid]);
         if (sa.x | sa.y | sa.z | sa.w) { acc.x += sa.x; acc.y += sa.y; acc.z += sa.z; acc.w += sa.w; acc_dirty = true; }
     }
@@ -814,13 +778,12 @@ __device__ __forceinline__ void play_role(
     __syncthreads();
     u32 total = push_count;
     u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
-    if (active)
-        for (u32 j = tid; j < total; j += TK_BLOCK) {              // list entry: episode to deal << 32 | slot in group
-            u32 en = push_list[j], t = en % TK_BLOCK;
-            lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
-        }
+    for (u32 j = tid; j < total; j += TK_BLOCK) {                  // list entry: episode to deal << 32 | slot in group
+        u32 en = push_list[j], t = en % TK_BLOCK;
+        lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
+    }
     if (tid == 0) rcount[TK_RC(group, par)] = total;
-    if (stamps && active && (tid & 63) == 0) {     // diagnostics only
+    if (stamps && (tid & 63) == 0) {     // diagnostics only
         u64 w = (u64)i >> 6;
         stamps[3 * w + 0] = t_real0;
         stamps[3 * w + 1] = __builtin_amdgcn_s_memrealtime();
@@ -836,22 +799,21 @@ __device__ __forceinline__ void play_role(
     }
 }
 
-// Two register budgets of the same kernel.  WIDE = true (the Bot-policy launches, every batch size): ~165 VGPRs,
-// nothing spills inside the card loops — still three waves per SIMD, and where the batch puts one wave on a
-// SIMD (65,536 games) a scratch reload would be a memory round trip that nothing hides; the next games' lines are
-// topped up early and the usual path falls through its branches (EARLY_LINES in play_role).  WIDE = false: at
-// most 128 VGPRs (the specialised card loops spill a little), four waves per SIMD: the external-action step,
-// and the Bot-policy build of rounds 1-2a that TAROK_WIDE_REGS=0 still selects for A/B runs (same-box medians,
-// G steps/s, wide | narrow: 262,144 games 160.9 | 155.3, 1 M 163.9 | 146.0, 4 M 175.9 | 169.3).
+// The Bot-policy kernel (tarok_krog_random; every batch size): ~165 VGPRs, nothing spills inside the card loops —
+// still three waves per SIMD, and where the batch puts one wave on a SIMD (65,536 games) a scratch reload would
+// be a memory round trip that nothing hides; the next games' lines are topped up early and the usual path falls
+// through its branches.  (Rounds 1-2 also shipped a 128-VGPR build of it, four waves per SIMD, slower at every
+// batch size — same-box medians, G steps/s, wide | narrow: 262,144 games 160.9 | 155.3, 1 M 163.9 | 146.0,
+// 4 M 175.9 | 169.3 — and selectable only through an environment variable: removed in round 3.)
 // HIST: also record the play history (one byte per card; tarok_create flag TAROK_HISTORY).
 #define TK_PLAY_ARGS                                                                                                             \
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,         \
-        const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
+        uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                                                           \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
         ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
         u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps
-template <bool RANDOM, bool HIST, bool WIDE>
-__device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
+template <bool HIST>
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
         refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
@@ -859,19 +821,195 @@ __device__ __forceinline__ void play_kernel_body(TK_PLAY_ARGS) {
 #ifdef TK_PLAY_PRIO                          // diagnostics build: wave priority of the play role (no effect: profiles/r02_ab_lone_wave_rewrite.txt)
         __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
 #endif
-        play_role<RANDOM, HIST, WIDE>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, cards, stride, count, epoch,
-                                action_in, action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
+        play_role<HIST>(blockIdx.x, threadIdx.x, n, seed, offset, mix, flags, cards, stride, count, epoch,
+                        action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
     }
 }
-#define TK_PLAY_FWD n, seed, offset, mix, flags, cards, stride, play_groups, epoch, fan, action_in, action_out, reward, done, trick, obs, \
-                    hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps
-template <bool RANDOM, bool HIST>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_play(TK_PLAY_ARGS) {
-    play_kernel_body<RANDOM, HIST, false>(TK_PLAY_FWD);
+
+// A game dealt here and now by the wave (deal_wave: all 64 lanes must come along) for the lanes with deal_here:
+// episode `ep` of slot i.  The rare path of a renewal: the slot's next-game line is missing or being re-dealt.
+__device__ __forceinline__ void deal_in_place_wave(bool deal_here, Game &gd, u64 &kd, u64 seed, u64 offset, int64_t i, u32 ep, int mix) {
+    u64 pend = __ballot(deal_here);
+    if (pend == 0) return;
+    u64 dkey = 0;
+    if (deal_here) dkey = game_key(seed, offset + (u64)i, ep);
+    u64 h0 = 0, h1 = 0, h2 = 0, h3 = 0, tal = 0;
+    u32 lane = __lane_id();
+    while (pend) {
+        int l = __builtin_ctzll(pend);
+        pend &= pend - 1;
+        u32 klo = (u32)__builtin_amdgcn_readlane((int)(u32)dkey, l);
+        u32 khi = (u32)__builtin_amdgcn_readlane((int)(u32)(dkey >> 32), l);
+        u64 w0, w1, w2, w3, wt;
+        deal_wave(klo, khi, w0, w1, w2, w3, wt);
+        if (lane == (u32)l) { h0 = w0; h1 = w1; h2 = w2; h3 = w3; tal = wt; }
+    }
+    if (deal_here) {
+        u32 cc, d, k;
+        sample_setup(dkey, mix, cc, d, k);
+        setup_game(gd, h0, h1, h2, h3, tal, cc, d, k);
+        gd.epar = TK_LINE(ep); gd.cprev = 0;
+        if (gd.phase == TK_PHASE_EXCHANGE) bot_exchange(gd, dkey);
+        kd = dkey;
+    }
 }
-template <bool RANDOM, bool HIST>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
-    play_kernel_body<RANDOM, HIST, true>(TK_PLAY_FWD);
+
+// THE ONE-CARD STEP (tarok_step, tarok_step_random, the env half of tarok_policy_step): the surface an external
+// policy drives, one card of every game per launch, the state through HBM on every card — the path SURVEY 8d's
+// 54 B/step describe.  Same results and the same refill protocol as play_role with cards = 1 (launches of both
+// kinds mix freely), but compiled on its own: no card loops, no scoring queue, no scratch — the generic kernel's
+// 128-VGPR build spilled twelve dwords per lane on this path, and a spilled dword is a store to memory: 47 of
+// the 82 bytes per step it wrote (profiles/r03_step_ledger.txt).
+//   Reads:  play pair 16 + seat pair 16 + the card 1 (RANDOM: the game's RNG key 8 instead).
+//   Writes: play pair 16 + observation word 8 (+ done 1, action 1, trick 2 where asked for);
+//           the seat pair (16) only by the lanes whose trick this card completed: every 4th card.
+//   A game that ENDS also touches its slot's Counters (32 B read, 32 B written), takes its successor from the
+//   slot's next-game line (64 B read), writes the successor's RNG key and puts one entry on the refill list.
+// SPEC = true (batches below 2^19 games: at most a wave or two per SIMD, a launch is latency bound): the lanes
+// that CAN end their game with this card — 4th card of a Berac trick or of a twelfth trick — issue those loads
+// next to the state load, before any rule work.  SPEC = false (streaming batches: the other waves of the SIMD
+// hide a dependent load): only the lanes that DID end it load them, after the rules — the speculative loads
+// were a fifth of the kernel's read traffic at 4 M games.
+template <bool RANDOM, bool SPEC>
+__device__ __forceinline__ void step_role(
+    u32 group, u32 tid, bool active, u32 a_reg,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 count, u32 *epoch,
+    const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
+    uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
+    __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
+    __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
+    __shared__ u32 push_count;
+    if (tid == 0) push_count = 0;
+    __syncthreads();
+    int64_t i = (int64_t)group * TK_BLOCK + tid;
+    bool valid = active && i < n;
+    int64_t ic = valid ? i : n - 1;
+    Game g;
+    load_game(g, s01, s23, ic);
+    u64 key = 0;
+    u32 a = 255;
+    if (RANDOM) key = gkey[ic]; else a = action_in ? action_in[ic] : a_reg;
+    const bool autoreset = (flags & TAROK_AUTO_RESET) != 0;
+    // next-game lines this launch may take: the `cprev` farthest ahead are being re-dealt right now (play_role)
+    const u32 cprev0 = valid ? g.cprev : 0u;
+    const u32 allowed = TK_AHEAD - min(cprev0, (u32)TK_AHEAD);
+    int4 acc = make_int4(0, 0, 0, 0);
+    u32 cur_ep = 0;
+    ulonglong2 na = make_ulonglong2(0, 0), nb = na;
+    u64 nkey = 0;
+    u32 ntag = 0;
+    bool have_line = false;
+    auto load_finish = [&](bool need) __attribute__((always_inline)) {
+        if (need) {
+            acc = cnt[i].score_sum;
+            cur_ep = cnt[i].episode;
+            if (autoreset && allowed > 0) {
+                const AuxLine *ln = &aux[i].line[TK_LINE(g.epar + 1)];
+                na = ln->n01; nb = ln->n23; nkey = ln->nkey; ntag = ln->nep;
+                have_line = true;
+            }
+        }
+    };
+    if constexpr (SPEC) {
+        bool berac = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
+        load_finish(valid && ((g.phase == TK_PHASE_PLAY && g.nt == 3 && (berac || g.trick_no == 11)) || g.phase == TK_PHASE_DONE));
+    }
+    const u32 par = launch_parity(count);    // (`count` was requested before the state: it has arrived with it)
+    launch_counted(epoch);
+    g.cprev = 0;
+    // ---- the card: krog's body (Klop.py:47-79, Navadna_igra.py:115-141), apply_step
+    const bool play = valid && g.phase == TK_PHASE_PLAY;
+    const u32 pos = g.trick_no * 4 + g.nt;                // cards played so far in this game
+    if (RANDOM) a = play ? policy_action(key, pos, legal_now(g)) : 255u;
+    u64 scores = 0;
+    u32 trick_info = 0;
+    int res = -2;
+    const u32 d_fin = g.declarer;
+    const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
+    if (play) res = apply_step<RANDOM, false>(g, a, scores, trick_info, trick != nullptr, nullptr);
+    const bool fin = res == 1;
+    // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): write-only here
+    if (hist && play && res >= 0) hist[(int64_t)pos * n + i] = (uint8_t)a;
+    bool seats_dirty = res >= 0 && g.nt == 0;
+    if (valid) {
+        if (RANDOM && action_out) TK_STREAM_STORE(&action_out[i], (uint8_t)a);
+        if (trick) TK_STREAM_STORE(&trick[i], (uint16_t)trick_info);
+    }
+    const bool renew = autoreset && valid && g.phase == TK_PHASE_DONE;     // (also a game finished by an earlier launch)
+    if constexpr (!SPEC) load_finish(fin || renew);
+    bool acc_dirty = false;
+    if (fin) {
+        if (reward) {
+            u64 rs = scores;
+            if ((flags & TAROK_REWARD_REF) && berac_fin) {
+                // what rezultat_igre folds into a Berac defender's last transition (Igralec.py:434-437):
+                // -20 when the hands are empty at the end (all twelve tricks were played), else +20
+                int dv = g.trick_no >= 12 ? -20 : 20;
+                rs = pack_scores(d_fin == 0 ? (int)(int16_t)(scores & 0xFFFF) : dv, d_fin == 1 ? (int)(int16_t)((scores >> 16) & 0xFFFF) : dv,
+                                 d_fin == 2 ? (int)(int16_t)((scores >> 32) & 0xFFFF) : dv, d_fin == 3 ? (int)(int16_t)(scores >> 48) : dv);
+            }
+            reinterpret_cast<u64 *>(reward)[i] = rs;
+        }
+        acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
+        acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
+        acc_dirty = true;
+    }
+    // ---- auto-reset: the successor comes out of the slot's next-game line (valid iff its tag is the game's
+    // number); without a usable line the wave deals the game here and the slot's lines are all refilled
+    u32 consumed = 0;
+    bool resync = false;
+    if (__ballot(renew) != 0) {                           // (wave uniform: deal_in_place_wave needs every lane)
+        bool swap = renew && have_line && ntag == cur_ep + 1;
+        if (swap) { unpack_fresh(g, na.x, na.y, nb.x, nb.y); key = nkey; }
+        bool deal_here = renew && !swap;
+        resync = deal_here && allowed > 0;                // a line that should have been usable was not
+        deal_in_place_wave(deal_here, g, key, seed, offset, i, cur_ep + 1, mix);
+        if (renew) { cur_ep++; consumed = 1; seats_dirty = true; }
+    }
+    if (valid) {
+        TK_STREAM_STORE(&obs[i], obs_word(g, fin));
+        if (done) TK_STREAM_STORE(&done[i], (uint8_t)(fin ? 1 : 0));
+    }
+    // ---- state back; the refill list of this launch (see play_role)
+    const u32 np = resync ? (u32)TK_AHEAD : consumed;
+    if (valid) {
+        g.cprev = np;                        // the next launch must not read those lines
+        if (acc_dirty) cnt[i].score_sum = acc;
+        if (consumed) { cnt[i].episode = cur_ep; gkey[i] = key; }
+        if (res != -2 || consumed || cprev0 != np) store_game(g, s01, s23, i, seats_dirty || cprev0 != np);
+    }
+    if (valid && np) {
+        u32 p0 = atomicAdd(&push_count, np);
+        push_ep[tid] = cur_ep;
+        for (u32 j = 0; j < np; j++) push_list[p0 + j] = (unsigned short)(j * TK_BLOCK + tid);
+    }
+    __syncthreads();
+    u32 total = push_count;
+    u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
+    if (active)
+        for (u32 j = tid; j < total; j += TK_BLOCK) {              // list entry: episode to deal << 32 | slot in group
+            u32 en = push_list[j], t = en % TK_BLOCK;
+            lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
+        }
+    if (tid == 0) rcount[TK_RC(group, par)] = total;
+}
+
+#define TK_STEP_ARGS                                                                                                              \
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,                                    \
+        const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
+        uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
+        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
+        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount
+template <bool RANDOM, bool SPEC>
+__global__ __launch_bounds__(TK_BLOCK) void k_step(TK_STEP_ARGS) {
+    u32 count = launch_count(epoch);
+    if (blockIdx.x >= play_groups)
+        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
+    else
+        step_role<RANDOM, SPEC>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
+                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1756,8 +1894,9 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
                    act_s);
     __syncthreads();
     u32 tid = threadIdx.x;
-    play_role<false, true>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags, 1, n,
-                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr);
+    // (speculative finish-path loads always: one 512-thread workgroup per CU, nothing else hides a dependent load)
+    step_role<false, true>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags,
+                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount);
 }
 
 #endif  // TK_BLOCK == 256
@@ -1882,9 +2021,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
-    e->wide_regs = true;                                      // (see k_play_wide)
-    if (const char *f = getenv("TAROK_WIDE_REGS")) e->wide_regs = atoi(f) != 0;      // diagnostics (A/B runs)
-    if (const char *f = getenv("TAROK_REFILL_FAN")) { int v = atoi(f); if (v >= 1 && v <= TK_REFILL_FAN) e->refill_fan = (uint32_t)v; }
+    e->spec_loads = n_games < (1 << 19);                      // (see step_role)
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
@@ -1927,6 +2064,15 @@ void tarok_destroy(tarok_env *e) {
 }
 
 int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
+
+int tarok_set_option(tarok_env *e, int option, int value) {
+    if (!e) return TAROK_EINVAL;
+    if (option == TAROK_OPT_SPEC_LOADS && (value == 0 || value == 1)) e->spec_loads = value != 0;
+    else if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) e->refill_fan = (uint32_t)value;
+    else return TAROK_EINVAL;
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }      // (the cached graph holds the old launches)
+    return TAROK_OK;
+}
 
 static inline void launch_prefetch(tarok_env *e, hipStream_t s) {
     dim3 grid((unsigned)((e->n + TK_PF_SLOTS - 1) / TK_PF_SLOTS));
@@ -1974,25 +2120,31 @@ int tarok_legal_actions(tarok_env *e, uint64_t *obs_out, int8_t *seat_out, void 
     return TAROK_OK;
 }
 
-// One play launch: play workgroups + as many refill workgroups (previous launch's lists).
+// One play launch: play workgroups + the refill workgroups that work the previous launch's lists off.
+// cards = 1 (tarok_step, tarok_step_random): the one-card kernel k_step; more cards: the Bot-policy card loops
+// of k_play_wide.
 static inline void launch_play(tarok_env *e, bool random, int cards, int64_t stride, const uint8_t *action_in,
                                uint8_t *action_out, int16_t *reward, uint8_t *done, uint16_t *trick, uint64_t *obs,
                                int flags, hipStream_t s) {
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
-    // (the external-policy kernel always carries the history code: one uniform test of `hist` per launch)
-#define TK_LAUNCH_PLAY(K, R, H)                                                                                        \
-    hipLaunchKernelGGL((K<R, H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
-                       groups, e->epoch, fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, \
+    if (cards == 1) {
+#define TK_LAUNCH_STEP(R, S)                                                                                             \
+    hipLaunchKernelGGL((k_step<R, S>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
+                       fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
+                       e->gkey, e->rlist, e->rcount)
+        if (random) { if (e->spec_loads) TK_LAUNCH_STEP(true, true); else TK_LAUNCH_STEP(true, false); }
+        else        { if (e->spec_loads) TK_LAUNCH_STEP(false, true); else TK_LAUNCH_STEP(false, false); }
+#undef TK_LAUNCH_STEP
+        return;
+    }
+#define TK_LAUNCH_PLAY(H)                                                                                              \
+    hipLaunchKernelGGL((k_play_wide<H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
+                       groups, e->epoch, fan, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01,            \
                        e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, e->stamps)
-    bool wide = e->wide_regs;                                 // (see k_play_wide)
-
-    if (!random) TK_LAUNCH_PLAY(k_play, false, true);
-    else if (e->hist) { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, true); else TK_LAUNCH_PLAY(k_play, true, true); }
-    else { if (wide) TK_LAUNCH_PLAY(k_play_wide, true, false); else TK_LAUNCH_PLAY(k_play, true, false); }
+    if (e->hist) TK_LAUNCH_PLAY(true); else TK_LAUNCH_PLAY(false);
 #undef TK_LAUNCH_PLAY
-
 }
 
 int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t *done_out, uint16_t *trick_out,

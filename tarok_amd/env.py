@@ -54,7 +54,10 @@ class Obs:
 
 
 class TarokVecEnv:
-    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False):
+    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False, spec_loads=None,
+                 refill_fan=None):
+        """spec_loads / refill_fan: launch tuning (tarok_set_option; None = the library's default for the
+        batch size); results never depend on them."""
         self._h = None
         L = _native.lib()
         if not torch.cuda.is_available() or L.tarok_device_count() == 0:
@@ -69,6 +72,15 @@ class TarokVecEnv:
         _native.check(L.tarok_create(C.byref(h), self.device_index, self.n, self.game_offset, self.seed, self.mix,
                                      K.HISTORY if history else 0))
         self._h = h
+        import os
+        if spec_loads is None and os.environ.get("TAROK_SPEC_LOADS"):      # diagnostics (tools/: A/B runs of whole scripts)
+            spec_loads = int(os.environ["TAROK_SPEC_LOADS"]) != 0
+        if refill_fan is None and os.environ.get("TAROK_REFILL_FAN"):
+            refill_fan = int(os.environ["TAROK_REFILL_FAN"])
+        if spec_loads is not None:
+            _native.check(L.tarok_set_option(h, K.OPT_SPEC_LOADS, 1 if spec_loads else 0))
+        if refill_fan is not None:
+            _native.check(L.tarok_set_option(h, K.OPT_REFILL_FAN, int(refill_fan)))
         with torch.cuda.device(self.device):
             self.obs_words = torch.zeros(self.n, dtype=torch.int64, device=self.device)
             self.reward = torch.zeros((self.n, 4), dtype=torch.int16, device=self.device)
@@ -207,15 +219,16 @@ class TarokVecEnv:
             self._kb_cards = cards
         return self._kb
 
-    def krog_random(self, cards=4, auto_reset=False, reward_ref=False):
+    def krog_random(self, cards=4, auto_reset=False, reward_ref=False, tricks=True):
         """`cards` cards of every game in one launch, Bot policy in-kernel (cards=4: one trick =
         one pass of the reference's krog).  Returns dict of [cards,N] tensors: action, reward
         [cards,N,4] (valid where done), done, trick, obs (observation words); also updates
-        self.obs_words to the last row."""
+        self.obs_words to the last row.  tricks=False: no per-trick rows (trick_out = NULL: the
+        set of outputs tarok_run_random asks for, i.e. the card loop the bench times)."""
         kb = self._krog_bufs(cards)
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_krog_random(self._h, int(cards), self.n, self._p(kb["action"]), self._p(kb["reward"]),
-                                                   self._p(kb["done"]), self._p(kb["trick"]), self._p(kb["obs"]),
+                                                   self._p(kb["done"]), self._p(kb["trick"]) if tricks else None, self._p(kb["obs"]),
                                                    (K.AUTO_RESET if auto_reset else 0) | (K.REWARD_REF if reward_ref else 0),
                                                    self._stream()))
             self.obs_words.copy_(kb["obs"][cards - 1])

@@ -260,23 +260,117 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     """tarok_run_random with auto-reset (wave-cooperative re-deal inside the step
     kernel), graph-replayed and eager, at 65,536 games x 192 steps vs the oracle."""
     n, seed, steps = 65536, 2, 192
-    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=8)
     # prefetch 4: every finished game is a 32-byte swap from the prefetched buffer;
     # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
-    for cards, chunk, pf in [(0, 48, 4), (1, 0, 0), (1, 64, 16), (0, 0, 2),
-                             (4, 48, 8), (4, 0, 4), (8, 96, 8), (16, 192, 16), (3, 48, 12), (48, 192, 48), (4, 64, 0), (8, 64, 0), (12, 48, 0),
-                             (24, 192, 0), (24, 96, 0), (32, 192, 0), (48, 192, 0), (48, 96, 0)]:   # 48 / 192 / 0 is the bench's headline mode
-        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    # spec: the one-card kernel's finish-path loads, speculative (the default at this size) or on demand
+    # (the bench's own launch shape, 128 cards x 65,536 games, is test_bench_launch_shape_vs_oracle)
+    for cards, chunk, pf, spec in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
+                                   (0, 48, 0, False), (1, 64, 0, False), (1, 0, 16, False), (0, 96, 0, True),
+                                   (4, 48, 8, None), (4, 0, 4, None), (8, 96, 8, None), (16, 192, 16, None), (3, 48, 12, None), (48, 192, 48, None),
+                                   (4, 64, 0, None), (8, 64, 0, None), (12, 48, 0, None),
+                                   (24, 192, 0, None), (24, 96, 0, None), (32, 192, 0, None), (48, 192, 0, None), (48, 96, 0, None)]:
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, spec_loads=spec)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
         ep, ss = env.counters()
-        cfg = (cards, chunk, pf)
+        cfg = (cards, chunk, pf, spec)
         assert (ep == ref["episode"]).all(), cfg
         assert (ss == ref["score_sum"]).all(), cfg
         assert (env.state() == ref["lanes"]).all(), cfg
         assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), cfg
         env.close()
+
+
+def test_step_api_streaming_size_vs_oracle(T, O, S):
+    """The one-card step at a batch size that streams (2^20 games: the library then issues the finish-path loads
+    on demand, TAROK_OPT_SPEC_LOADS = 0 by default): the two-kernel external-policy path and tarok_step_random,
+    graph-replayed, 96 lock-steps with auto-reset vs the oracle — every slot's episode number, score sums,
+    canonical state and observation word."""
+    n, seed, steps = 1 << 20, 9, 96
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
+    for cards in (0, 1):
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+        env.reset()
+        env.run_random(steps, cards_per_launch=cards, graph_chunk=48, auto_reset=True)
+        ep, ss = env.counters()
+        assert (ep == ref["episode"]).all(), cards
+        assert (ss == ref["score_sum"]).all(), cards
+        assert (env.state() == ref["lanes"]).all(), cards
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), cards
+        env.close()
+
+
+def test_bench_launch_shape_vs_oracle(T, O, S):
+    """The launch shape bench.py times, exactly: 65,536 games (seed 0, MIX_ALL), 128 cards per launch, ONE
+    hipGraph of 20 launches through tarok_run_random (action / done / obs rows written, no trick rows: the
+    trick-aligned STD card loop of k_play_wide), captured + replayed, then replayed again (the bench's timed
+    region replays the graph its warm-up captured): episode numbers, score sums, canonical state and
+    observation words of all 65,536 slots equal the oracle's after 2,560 and after 5,120 lock-steps."""
+    n, seed, cards, launches = 65536, 0, 128, 20
+    steps = cards * launches
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    env.reset()
+    for k in (1, 2):
+        env.run_random(steps, cards_per_launch=cards, graph_chunk=steps, auto_reset=True)
+        ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, k * steps, threads=16)
+        ep, ss = env.counters()
+        assert (ep == ref["episode"]).all(), k
+        assert (ss == ref["score_sum"]).all(), k
+        assert (env.state() == ref["lanes"]).all(), k
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), k
+    env.close()
+
+
+@pytest.mark.parametrize("cards,tricks", [(128, False), (192, False), (128, True)])
+def test_long_launch_rows_vs_oracle_trace(T, O, S, cards, tricks):
+    """EVERY per-card output row of long launches (128 = the bench's, 192 = the longest) at 65,536 games: two
+    consecutive tarok_krog_random launches after a lead-in launch; for a 1-in-64 sample of the slots the
+    oracle replays the slot from the env state at the first launch's start, through the auto-resets (next
+    game = episode + 1 of the slot), and row c of action / obs / done / reward (/ trick) must be what the
+    oracle's c-th card gives: the Bot policy's card on the spec RNG, the next observation word, the done
+    flag, the scores of a game that ends, what rezultat_stiha is told.  tricks = False is the set of outputs
+    tarok_run_random asks for (the card loop the bench times)."""
+    n, seed = 65536, 3
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    env.reset()
+    env.run_random(cards, cards_per_launch=cards, graph_chunk=0, auto_reset=True)      # lead-in: slots mid-run, lines consumed
+    lanes0 = env.state()
+    ep0, ss0 = env.counters()
+    rows = dict(action=[], obs=[], done=[], reward=[], trick=[])
+    for launch in range(2):
+        kb = env.krog_random(cards, auto_reset=True, tricks=tricks)
+        for k in rows:
+            rows[k].append(kb[k].cpu().numpy().copy())
+    act = np.concatenate(rows["action"]); obs = np.concatenate(rows["obs"]).view(np.uint64)
+    done = np.concatenate(rows["done"]).astype(bool); reward = np.concatenate(rows["reward"])
+    trick = np.concatenate(rows["trick"]).view(np.uint16)
+    ep1, ss1 = env.counters()
+    lanes1 = env.state()
+    for i in range(0, n, 64):
+        g = O.Game.from_lanes(lanes0[:, i])
+        ep = int(ep0[i])
+        key = O.game_key(seed, i, ep)
+        ssum = ss0[i].astype(np.int64).copy()
+        for t in range(2 * cards):
+            a = O.policy_action(key, g.g.trick_no * 4 + g.g.n_in_trick, g.legal())
+            assert int(act[t, i]) == a, (i, t)
+            assert g.step(a) >= 0, (i, t)
+            fin = g.done
+            assert bool(done[t, i]) == fin, (i, t)
+            if tricks:
+                assert int(trick[t, i]) == int(g.g.last_trick), (i, t)
+            if fin:
+                assert reward[t, i].tolist() == g.scores, (i, t)
+                ssum += np.array(g.scores)
+                ep += 1
+                g = O.Game.synth(seed, i, ep, S.MIX_ALL)
+                key = O.game_key(seed, i, ep)
+            assert g.obs_word(fin) == int(obs[t, i]), (i, t)
+        assert ep == int(ep1[i]) and (ssum == ss1[i]).all(), i
+        assert (g.lanes() == lanes1[:, i]).all(), i
+    env.close()
 
 
 def test_long_launches_vs_oracle(T, O, S):
@@ -286,7 +380,7 @@ def test_long_launches_vs_oracle(T, O, S):
     an extra prefetch after every launch and without (the lines then come from the refill workgroups alone), 16,384 games x 1,920 lock-steps vs the
     oracle: episode numbers, score sums, canonical state, observation words."""
     n, seed, steps = 16384, 5, 1920
-    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps)
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=8)
     for cards, chunk, pf in [(128, 640, 128), (128, 0, 0), (160, 960, 0), (192, 1920, 0), (64, 640, 64)]:
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
         env.reset()
@@ -962,19 +1056,20 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
     env.close()
 
 
-@pytest.mark.parametrize("mixname", ["all", "berac"])
-def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname):
+@pytest.mark.parametrize("mixname,spec", [("all", None), ("berac", None), ("all", False), ("berac", False)])
+def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname, spec):
     """Model-based fuzz: a random sequence of API calls (one-card steps with legal / illegal /
     garbage cards, in-kernel-policy steps, 1..48 cards per launch, auto-reset on and off, resets)
     on the GPU env vs the same sequence applied slot by slot to the CPU oracle; canonical state,
     observation words, episode numbers and score sums compared after every call.  The all-Berac
     mix makes slots finish several games inside one launch (swap-ins from more than one
-    next-game line, lines on a refill list, games dealt in place)."""
+    next-game line, lines on a refill list, games dealt in place).  spec = False: the one-card kernel with
+    its finish-path loads on demand (the build that streaming batch sizes get)."""
     import ctypes as C
     rnd = np.random.RandomState(12345)
     n, seed, mix = 768, 77, (S.MIX_ALL if mixname == "all" else S.MIX_FIXED + 7)
     L = O.lib()
-    env = T.TarokVecEnv(n, seed=seed, mix=mix)
+    env = T.TarokVecEnv(n, seed=seed, mix=mix, spec_loads=spec)
 
     class Slot:
         pass
