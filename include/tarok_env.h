@@ -96,15 +96,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
 void tarok_destroy(tarok_env *env);
 int64_t tarok_num_games(const tarok_env *env);
 
-/* Launch tuning of an env; the results never depend on it (the parity tests run every setting).
- * Both default from the batch size at tarok_create.
- *   TAROK_OPT_SPEC_LOADS  one-card step (tarok_step / tarok_step_random): 1 = the lanes that CAN end their
- *                         game with this card load their slot's counters and next-game line next to the state
- *                         (one memory round trip per launch: latency-bound batches; default below 2^19 games),
- *                         0 = only the lanes that DID end it load them, after the rules (fewer bytes:
- *                         streaming batches)
+/* Launch tuning of an env; the results never depend on it.  Defaults from the batch size at tarok_create.
  *   TAROK_OPT_REFILL_FAN  1..8 play workgroups whose refill lists one refill workgroup works off */
-#define TAROK_OPT_SPEC_LOADS 1
 #define TAROK_OPT_REFILL_FAN 2
 int tarok_set_option(tarok_env *env, int option, int value);
 

@@ -107,7 +107,6 @@ struct tarok_env {
     u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
-    bool spec_loads;         // one-card step: finish-path loads issued speculatively next to the state load (step_role)
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -865,23 +864,30 @@ __device__ __forceinline__ void deal_in_place_wave(bool deal_here, Game &gd, u64
 //           the seat pair (16) only by the lanes whose trick this card completed: every 4th card.
 //   A game that ENDS also touches its slot's Counters (32 B read, 32 B written), takes its successor from the
 //   slot's next-game line (64 B read), writes the successor's RNG key and puts one entry on the refill list.
-// SPEC = true (batches below 2^19 games: at most a wave or two per SIMD, a launch is latency bound): the lanes
-// that CAN end their game with this card — 4th card of a Berac trick or of a twelfth trick — issue those loads
-// next to the state load, before any rule work.  SPEC = false (streaming batches: the other waves of the SIMD
-// hide a dependent load): only the lanes that DID end it load them, after the rules — the speculative loads
-// were a fifth of the kernel's read traffic at 4 M games.
-template <bool RANDOM, bool SPEC>
+// Finished games are scored on DENSE lanes: about a tenth of the slots end a game on a trick's 4th card, so every
+// wave would run the scoring code (both contract families, ~270 instructions) for six active lanes — measured at
+// 4 M games, the finishing lanes of a mixed batch cost 116 ps each against 40 ps in an all-Klop batch, where all
+// lanes end together (profiles/r03_step_durations.txt).  A lane whose game ends leaves the final state and the
+// slot's score sums in a workgroup-wide LDS list (FINQ_WORDS words per entry) and goes on to the renewal; after
+// the role's one barrier the first threads of the workgroup score the list, one entry per lane, and write the
+// reward rows and the score sums.  Nothing a lane does after the card depends on the scores.
+// Only the lanes whose game DID end load those, after the rules (the scoring list is filled meanwhile).  Rounds 1-2
+// had every lane that CAN end its game with this card — 4th card of a Berac trick or of a twelfth trick, a fifth of
+// the lanes of such a launch — issue them speculatively next to the state load: 5.3 B/step more read traffic at
+// 4 M games, and no faster at any batch size, 65,536 games included (profiles/r03_ab_step.txt).
+#define FINQ_WORDS 13
+template <bool RANDOM>
 __device__ __forceinline__ void step_role(
     u32 group, u32 tid, bool active, u32 a_reg,
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 count, u32 *epoch,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u32 (*__restrict__ finq)[TK_BLOCK] /* LDS [FINQ_WORDS][TK_BLOCK] */) {
     __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
     __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
-    __shared__ u32 push_count;
-    if (tid == 0) push_count = 0;
+    __shared__ u32 push_count, fin_count;
+    if (tid == 0) { push_count = 0; fin_count = 0; }
     __syncthreads();
     int64_t i = (int64_t)group * TK_BLOCK + tid;
     bool valid = active && i < n;
@@ -912,10 +918,6 @@ __device__ __forceinline__ void step_role(
             }
         }
     };
-    if constexpr (SPEC) {
-        bool berac = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-        load_finish(valid && ((g.phase == TK_PHASE_PLAY && g.nt == 3 && (berac || g.trick_no == 11)) || g.phase == TK_PHASE_DONE));
-    }
     const u32 par = launch_parity(count);    // (`count` was requested before the state: it has arrived with it)
     launch_counted(epoch);
     g.cprev = 0;
@@ -926,9 +928,8 @@ __device__ __forceinline__ void step_role(
     u64 scores = 0;
     u32 trick_info = 0;
     int res = -2;
-    const u32 d_fin = g.declarer;
-    const bool berac_fin = g.contract == TK_BERAC || g.contract == TK_ODPRTI_BERAC;
-    if (play) res = apply_step<RANDOM, false>(g, a, scores, trick_info, trick != nullptr, nullptr);
+    // (a finished game is scored after the barrier, from its final state, on dense lanes)
+    if (play) res = apply_step<RANDOM, true>(g, a, scores, trick_info, trick != nullptr, nullptr);
     const bool fin = res == 1;
     // the play history (zgodovina, Klop.py:63 / Navadna_igra.py:127): write-only here
     if (hist && play && res >= 0) hist[(int64_t)pos * n + i] = (uint8_t)a;
@@ -938,23 +939,15 @@ __device__ __forceinline__ void step_role(
         if (trick) TK_STREAM_STORE(&trick[i], (uint16_t)trick_info);
     }
     const bool renew = autoreset && valid && g.phase == TK_PHASE_DONE;     // (also a game finished by an earlier launch)
-    if constexpr (!SPEC) load_finish(fin || renew);
-    bool acc_dirty = false;
-    if (fin) {
-        if (reward) {
-            u64 rs = scores;
-            if ((flags & TAROK_REWARD_REF) && berac_fin) {
-                // what rezultat_igre folds into a Berac defender's last transition (Igralec.py:434-437):
-                // -20 when the hands are empty at the end (all twelve tricks were played), else +20
-                int dv = g.trick_no >= 12 ? -20 : 20;
-                rs = pack_scores(d_fin == 0 ? (int)(int16_t)(scores & 0xFFFF) : dv, d_fin == 1 ? (int)(int16_t)((scores >> 16) & 0xFFFF) : dv,
-                                 d_fin == 2 ? (int)(int16_t)((scores >> 32) & 0xFFFF) : dv, d_fin == 3 ? (int)(int16_t)(scores >> 48) : dv);
-            }
-            reinterpret_cast<u64 *>(reward)[i] = rs;
-        }
-        acc.x += (int16_t)(scores & 0xFFFF); acc.y += (int16_t)((scores >> 16) & 0xFFFF);
-        acc.z += (int16_t)((scores >> 32) & 0xFFFF); acc.w += (int16_t)(scores >> 48);
-        acc_dirty = true;
+    load_finish(fin || renew);
+    if (fin) {                                            // the final state goes on the scoring list (the loads above are in flight)
+        u32 e = atomicAdd(&fin_count, 1u);
+        finq[0][e] = TK_LO(g.A); finq[1][e] = TK_HI(g.A); finq[2][e] = TK_LO(g.B); finq[3][e] = TK_HI(g.B);
+        finq[4][e] = TK_LO(g.C); finq[5][e] = TK_HI(g.C); finq[6][e] = TK_LO(g.talon);
+        finq[7][e] = g.contract | (g.declarer << 4) | (g.king << 6) | (g.team << 8) | (g.tl << 12) | (g.trick_no << 16) | (g.leader << 20) |
+                     (TK_HI(g.talon) << 24);
+        finq[8][e] = tid;
+        finq[9][e] = (u32)acc.x; finq[10][e] = (u32)acc.y; finq[11][e] = (u32)acc.z; finq[12][e] = (u32)acc.w;
     }
     // ---- auto-reset: the successor comes out of the slot's next-game line (valid iff its tag is the game's
     // number); without a usable line the wave deals the game here and the slot's lines are all refilled
@@ -976,7 +969,6 @@ __device__ __forceinline__ void step_role(
     const u32 np = resync ? (u32)TK_AHEAD : consumed;
     if (valid) {
         g.cprev = np;                        // the next launch must not read those lines
-        if (acc_dirty) cnt[i].score_sum = acc;
         if (consumed) { cnt[i].episode = cur_ep; gkey[i] = key; }
         if (res != -2 || consumed || cprev0 != np) store_game(g, s01, s23, i, seats_dirty || cprev0 != np);
     }
@@ -986,6 +978,34 @@ __device__ __forceinline__ void step_role(
         for (u32 j = 0; j < np; j++) push_list[p0 + j] = (unsigned short)(j * TK_BLOCK + tid);
     }
     __syncthreads();
+    // ---- the games that ended with this card, scored one per lane: final_scores from the final state alone
+    // (Klop.py:36-45, Berac.py:33-44, Navadna_igra.py:80-113); reward row and score sums of the slot
+    if (active)
+        for (u32 e = tid, nf = fin_count; e < nf; e += TK_BLOCK) {
+            Game f;
+            f.A = TK_U64(finq[0][e], finq[1][e]); f.B = TK_U64(finq[2][e], finq[3][e]); f.C = TK_U64(finq[4][e], finq[5][e]);
+            u32 m = finq[7][e], t = finq[8][e];
+            f.talon = TK_U64(finq[6][e], (m >> 24) & 15u);
+            f.contract = m & 15; f.declarer = (m >> 4) & 3; f.king = (m >> 6) & 3; f.team = (m >> 8) & 15;
+            f.tl = (m >> 12) & 7; f.trick_no = (m >> 16) & 15; f.leader = (m >> 20) & 3;
+            f.trick = 0; f.nt = 0; f.phase = TK_PHASE_DONE; f.error = 0; f.epar = 0; f.cprev = 0;
+            u64 sc = final_scores(f);
+            int64_t it = (int64_t)group * TK_BLOCK + t;
+            if (reward) {
+                u64 rs = sc;
+                if ((flags & TAROK_REWARD_REF) && (f.contract == TK_BERAC || f.contract == TK_ODPRTI_BERAC)) {
+                    // what rezultat_igre folds into a Berac defender's last transition (Igralec.py:434-437):
+                    // -20 when the hands are empty at the end (all twelve tricks were played), else +20
+                    int dv = f.trick_no >= 12 ? -20 : 20;
+                    u32 d = f.declarer;
+                    rs = pack_scores(d == 0 ? (int)(int16_t)(sc & 0xFFFF) : dv, d == 1 ? (int)(int16_t)((sc >> 16) & 0xFFFF) : dv,
+                                     d == 2 ? (int)(int16_t)((sc >> 32) & 0xFFFF) : dv, d == 3 ? (int)(int16_t)(sc >> 48) : dv);
+                }
+                reinterpret_cast<u64 *>(reward)[it] = rs;
+            }
+            cnt[it].score_sum = make_int4((int)finq[9][e] + (int16_t)(sc & 0xFFFF), (int)finq[10][e] + (int16_t)((sc >> 16) & 0xFFFF),
+                                          (int)finq[11][e] + (int16_t)((sc >> 32) & 0xFFFF), (int)finq[12][e] + (int16_t)(sc >> 48));
+        }
     u32 total = push_count;
     u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
     if (active)
@@ -1002,14 +1022,23 @@ __device__ __forceinline__ void step_role(
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
         ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
         u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount
-template <bool RANDOM, bool SPEC>
-__global__ __launch_bounds__(TK_BLOCK) void k_step(TK_STEP_ARGS) {
+#ifndef TK_STEP_WAVES
+#define TK_STEP_WAVES 4            // waves per SIMD the one-card kernel is compiled for (diagnostic builds: 5, 6, 8)
+#endif
+template <bool RANDOM>
+__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STEP_WAVES))) void k_step(TK_STEP_ARGS) {
     u32 count = launch_count(epoch);
-    if (blockIdx.x >= play_groups)
-        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
+    // The refill workgroups are spread among the play workgroups — block q (fan + 1) works the lists of the `fan`
+    // play groups in the blocks after it off — so that their deals (instruction bound, ~2.7k per game) run UNDER the
+    // play workgroups' streaming instead of after it: at the end of the grid they were a 24 us tail of every
+    // launch that follows a trick's last card at 4 M games (profiles/r03_step_durations.txt).
+    __shared__ u32 finq[FINQ_WORDS][TK_BLOCK];
+    u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
+    if (r == 0)
+        refill_role(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
     else
-        step_role<RANDOM, SPEC>(blockIdx.x, threadIdx.x, true, 255u, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
-                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount);
+        step_role<RANDOM>(blockIdx.x - q - 1, threadIdx.x, true, 255u, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
+                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, finq);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1672,7 +1701,7 @@ __device__ __forceinline__ void policy_body(
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
     uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps,
-    uint8_t *__restrict__ act_s) {
+    uint8_t *__restrict__ act_s, u32 **lds_after = nullptr /* the activation buffer: free once every thread has returned */) {
     constexpr int GAMES = PM_M * TILES;
     u64 ts[7];
 #define PM_STAMP(k) if (stamps) ts[k] = __builtin_amdgcn_s_memtime();
@@ -1682,6 +1711,7 @@ __device__ __forceinline__ void policy_body(
     int64_t base = (int64_t)blockIdx.x * GAMES;
     u32 tid = threadIdx.x, wave4 = (tid >> 6) & 3, tile = tid >> 8;
     __bf16 *Xt = X + tile * PM_M * PM_LD;
+    if (lds_after) *lds_after = reinterpret_cast<u32 *>(X);
     bf16x8 wq[4][2];
     mlp_prefetch(wq, w1, wave4 * 2);           // lands while the features are built
     // ---- the four 64-bit feature words of each game (same definition as k_observe)
@@ -1890,13 +1920,14 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
         return;
     }
     __shared__ uint8_t act_s[2 * PM_M];
+    u32 *lds = nullptr;
     policy_body<2>(n, s01, s23, obs_in, gkey, w1, b1, w2, b2, w3, b3, action, logp, value, nullptr, feature_words_out, nullptr,
-                   act_s);
-    __syncthreads();
+                   act_s, &lds);
+    __syncthreads();                          // (the policy's LDS is free from here on: the step's scoring list goes there)
     u32 tid = threadIdx.x;
-    // (speculative finish-path loads always: one 512-thread workgroup per CU, nothing else hides a dependent load)
-    step_role<false, true>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags,
-                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount);
+    step_role<false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags,
+                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount,
+                           reinterpret_cast<u32 (*)[TK_BLOCK]>(lds));
 }
 
 #endif  // TK_BLOCK == 256
@@ -2021,7 +2052,6 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
-    e->spec_loads = n_games < (1 << 19);                      // (see step_role)
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
@@ -2067,8 +2097,7 @@ int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
 
 int tarok_set_option(tarok_env *e, int option, int value) {
     if (!e) return TAROK_EINVAL;
-    if (option == TAROK_OPT_SPEC_LOADS && (value == 0 || value == 1)) e->spec_loads = value != 0;
-    else if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) e->refill_fan = (uint32_t)value;
+    if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) e->refill_fan = (uint32_t)value;
     else return TAROK_EINVAL;
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }      // (the cached graph holds the old launches)
     return TAROK_OK;
@@ -2130,12 +2159,11 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     if (cards == 1) {
-#define TK_LAUNCH_STEP(R, S)                                                                                             \
-    hipLaunchKernelGGL((k_step<R, S>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
+#define TK_LAUNCH_STEP(R)                                                                                                \
+    hipLaunchKernelGGL((k_step<R>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
                        fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
                        e->gkey, e->rlist, e->rcount)
-        if (random) { if (e->spec_loads) TK_LAUNCH_STEP(true, true); else TK_LAUNCH_STEP(true, false); }
-        else        { if (e->spec_loads) TK_LAUNCH_STEP(false, true); else TK_LAUNCH_STEP(false, false); }
+        if (random) TK_LAUNCH_STEP(true); else TK_LAUNCH_STEP(false);
 #undef TK_LAUNCH_STEP
         return;
     }

@@ -54,10 +54,9 @@ class Obs:
 
 
 class TarokVecEnv:
-    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False, spec_loads=None,
-                 refill_fan=None):
-        """spec_loads / refill_fan: launch tuning (tarok_set_option; None = the library's default for the
-        batch size); results never depend on them."""
+    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False, refill_fan=None):
+        """refill_fan: launch tuning (tarok_set_option; None = the library's default for the batch size);
+        results never depend on it."""
         self._h = None
         L = _native.lib()
         if not torch.cuda.is_available() or L.tarok_device_count() == 0:
@@ -73,12 +72,8 @@ class TarokVecEnv:
                                      K.HISTORY if history else 0))
         self._h = h
         import os
-        if spec_loads is None and os.environ.get("TAROK_SPEC_LOADS"):      # diagnostics (tools/: A/B runs of whole scripts)
-            spec_loads = int(os.environ["TAROK_SPEC_LOADS"]) != 0
-        if refill_fan is None and os.environ.get("TAROK_REFILL_FAN"):
+        if refill_fan is None and os.environ.get("TAROK_REFILL_FAN"):      # diagnostics (tools/: A/B runs of whole scripts)
             refill_fan = int(os.environ["TAROK_REFILL_FAN"])
-        if spec_loads is not None:
-            _native.check(L.tarok_set_option(h, K.OPT_SPEC_LOADS, 1 if spec_loads else 0))
         if refill_fan is not None:
             _native.check(L.tarok_set_option(h, K.OPT_REFILL_FAN, int(refill_fan)))
         with torch.cuda.device(self.device):

@@ -43,7 +43,7 @@ AUTO_RESET = 2
 CLEAR_COUNTERS = 4
 REWARD_REF = 8           # step: reward_out = what rezultat_igre folds into the last transition (Igralec.py:421-437)
 HISTORY = 16             # TarokVecEnv(history=True): keep the play history (needed by observe_ref)
-OPT_SPEC_LOADS, OPT_REFILL_FAN = 1, 2    # tarok_set_option
+OPT_REFILL_FAN = 2        # tarok_set_option
 
 # the reference-layout observation record (include/tarok_env.h TAROK_REF_*)
 REF_ROWS = 56

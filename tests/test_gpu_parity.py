@@ -264,18 +264,18 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # prefetch 4: every finished game is a 32-byte swap from the prefetched buffer;
     # 0: every one is dealt by the wave inside the step kernel; 16: a mixture.
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
-    # spec: the one-card kernel's finish-path loads, speculative (the default at this size) or on demand
+    # fan: refill lists per refill workgroup (tarok_set_option; None = the default for the size, 1)
     # (the bench's own launch shape, 128 cards x 65,536 games, is test_bench_launch_shape_vs_oracle)
-    for cards, chunk, pf, spec in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
-                                   (0, 48, 0, False), (1, 64, 0, False), (1, 0, 16, False), (0, 96, 0, True),
-                                   (4, 48, 8, None), (4, 0, 4, None), (8, 96, 8, None), (16, 192, 16, None), (3, 48, 12, None), (48, 192, 48, None),
-                                   (4, 64, 0, None), (8, 64, 0, None), (12, 48, 0, None),
-                                   (24, 192, 0, None), (24, 96, 0, None), (32, 192, 0, None), (48, 192, 0, None), (48, 96, 0, None)]:
-        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, spec_loads=spec)
+    for cards, chunk, pf, fan in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
+                                  (0, 48, 0, 8), (1, 64, 0, 3), (1, 0, 16, 8), (0, 96, 0, 4),
+                                  (4, 48, 8, None), (4, 0, 4, None), (8, 96, 8, None), (16, 192, 16, None), (3, 48, 12, None), (48, 192, 48, None),
+                                  (4, 64, 0, None), (8, 64, 0, 5), (12, 48, 0, None),
+                                  (24, 192, 0, None), (24, 96, 0, None), (32, 192, 0, None), (48, 192, 0, None), (48, 96, 0, None)]:
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, refill_fan=fan)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
         ep, ss = env.counters()
-        cfg = (cards, chunk, pf, spec)
+        cfg = (cards, chunk, pf, fan)
         assert (ep == ref["episode"]).all(), cfg
         assert (ss == ref["score_sum"]).all(), cfg
         assert (env.state() == ref["lanes"]).all(), cfg
@@ -284,8 +284,8 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
 
 
 def test_step_api_streaming_size_vs_oracle(T, O, S):
-    """The one-card step at a batch size that streams (2^20 games: the library then issues the finish-path loads
-    on demand, TAROK_OPT_SPEC_LOADS = 0 by default): the two-kernel external-policy path and tarok_step_random,
+    """The one-card step at a batch size that streams (2^20 games; eight refill lists per refill workgroup, spread
+    among the play workgroups): the two-kernel external-policy path and tarok_step_random,
     graph-replayed, 96 lock-steps with auto-reset vs the oracle — every slot's episode number, score sums,
     canonical state and observation word."""
     n, seed, steps = 1 << 20, 9, 96
@@ -1056,20 +1056,20 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
     env.close()
 
 
-@pytest.mark.parametrize("mixname,spec", [("all", None), ("berac", None), ("all", False), ("berac", False)])
-def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname, spec):
+@pytest.mark.parametrize("mixname,fan", [("all", None), ("berac", None), ("berac", 3)])
+def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname, fan):
     """Model-based fuzz: a random sequence of API calls (one-card steps with legal / illegal /
     garbage cards, in-kernel-policy steps, 1..48 cards per launch, auto-reset on and off, resets)
     on the GPU env vs the same sequence applied slot by slot to the CPU oracle; canonical state,
     observation words, episode numbers and score sums compared after every call.  The all-Berac
     mix makes slots finish several games inside one launch (swap-ins from more than one
-    next-game line, lines on a refill list, games dealt in place).  spec = False: the one-card kernel with
-    its finish-path loads on demand (the build that streaming batch sizes get)."""
+    next-game line, lines on a refill list, games dealt in place).  fan: refill lists per refill workgroup
+    (three lists of a 768-slot env: one refill workgroup among three play workgroups)."""
     import ctypes as C
     rnd = np.random.RandomState(12345)
     n, seed, mix = 768, 77, (S.MIX_ALL if mixname == "all" else S.MIX_FIXED + 7)
     L = O.lib()
-    env = T.TarokVecEnv(n, seed=seed, mix=mix, spec_loads=spec)
+    env = T.TarokVecEnv(n, seed=seed, mix=mix, refill_fan=fan)
 
     class Slot:
         pass

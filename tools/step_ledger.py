@@ -17,10 +17,8 @@ from tarok_amd import TarokVecEnv, _native, karte as K
 n, mode, spec, want_done, want_reward = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4] == "1", sys.argv[5] == "1"
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 96
 L = _native.lib()
-kw = {}
-if spec != "d" and hasattr(L, "tarok_set_option"):
-    kw["spec_loads"] = spec == "1"
-env = TarokVecEnv(n, seed=0, mix=K.MIX_ALL, **kw)
+kw = {}          # (<spec> selected the finish-path load mode while both existed: profiles/r03_step_ledger.txt; ignored now)
+env = TarokVecEnv(n, seed=0, mix=int(os.environ.get("TAROK_LEDGER_MIX", K.MIX_ALL)), **kw)     # (16 = all Klop: games end together, every 48 cards)
 env.reset()
 P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 s = C.c_void_p(torch.cuda.current_stream(env.device).cuda_stream)

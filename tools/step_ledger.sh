@@ -9,7 +9,7 @@ TAG=${2:-ledger}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-run() {   # name lib mode spec done reward
+run() {   # name lib mode - done reward
   for C in FETCH_SIZE WRITE_SIZE; do
     d=$OUT/$1_$C
     if [ -n "$2" ]; then export TAROK_LIB=$2; else unset TAROK_LIB; fi
@@ -20,8 +20,6 @@ run() {   # name lib mode spec done reward
 run two_base "" two d 1 1
 run two_nodone "" two d 0 1
 run two_noreward "" two d 1 0
-run two_spec1 "" two 1 1 1
-run two_spec0 "" two 0 1 1
 run random_base "" random d 1 1
 if [ -f tools/ab/r02.so ]; then
   run two_r02 tools/ab/r02.so two d 1 1

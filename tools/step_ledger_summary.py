@@ -54,7 +54,8 @@ def main():
     print("array by array (differences between variants, bytes per env step):")
     print("  done row (1 B):                       W %.2f" % d("two_base", "two_nodone", "stepW"))
     print("  reward rows of finished games:        W %.2f" % d("two_base", "two_noreward", "stepW"))
-    print("  speculative finish-path loads:        R %.2f   (SPEC on - off; 4th-card launches: %.2f)" % (d("two_spec1", "two_spec0", "stepR"), d("two_spec1", "two_spec0", "stepR", 2)))
+    if "two_spec1" in table:            # (round 3's first passes, while the speculative finish-path loads still existed)
+        print("  speculative finish-path loads:        R %.2f   (SPEC on - off; 4th-card launches: %.2f)" % (d("two_spec1", "two_spec0", "stepR"), d("two_spec1", "two_spec0", "stepR", 2)))
     if "two_base" in table and "stepW" in table["two_base"]:
         r = table["two_base"]
         print("  4th card on top of cards 0-2:         R %.2f  W %.2f per 4th-card launch (seat pair 16 W; Counters, next-game line, key, list entry of the games that end)"
