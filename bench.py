@@ -22,8 +22,12 @@ graph, so that the capture is untimed, and to ~25 ms of launches, so that the GP
 idle clocks: `warmup` reports what ran).  Weak scaling: each rank
 owns its own 65,536 games (global game indices rank*65536...), no collective in the env path.
 
+BASELINE.md's protocol: `value` is the first timed region (seed 0: the contract's number); the further
+regions of --repeats rotate the seeds {0, 1, 2} (one env per seed, each warmed up and graph-captured untimed)
+and are reported as a spread and per seed.
+
 Extra objects on the JSON line:
-  roofline           the dominant kernel (k_play<true>) against HBM peak.  `achieved` =
+  roofline           the dominant kernel (k_play_wide: tarok_krog_random) against HBM peak.  `achieved` =
                      HBM bytes per launch / launch duration (HIP events on the launch stream
                      over the timed region / launches).  For launches of several cards the
                      bytes are the MEASURED ones (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE of
@@ -31,9 +35,11 @@ Extra objects on the JSON line:
                      does not move the 54 algorithmic B/step of SURVEY 8d, which are reported
                      beside it as `algorithmic` (that figure is not a bound: it can exceed 1).
   roofline_step_api  the reset()/step()/legal_actions() surface an external policy drives
-                     (tarok_policy_random + tarok_step, one card per launch), where 54 B/step
-                     IS the right accounting.
-  issue_roofline     what really bounds k_play<true>: instruction issue (the play role's
+                     (tarok_policy_random + tarok_step, one card per launch: k_policy + k_step), where
+                     54 B/step IS the right accounting; `streaming` = the same path at 4 M games, where
+                     the batch streams through HBM (at 65,536 games a launch is latency bound).
+  config2            BASELINE configs[1]: 4,096 Tri / Dve / Ena games, the headline mode and the step API.
+  issue_roofline     what really bounds k_play_wide: instruction issue (the play role's
                      instruction count per step from the committed SQ counters x the measured
                      issue cost per instruction from tools/valu_issue.hip).
   cpu_baseline       the CPU oracle (oracle/, a C port of the reference rules — test
@@ -55,7 +61,9 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_STEP = 54
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
-PROFILE_TAG = "r02"             # profiles/<tag>_* are the files read below
+PROFILE_TAG = "r03"             # profiles/<tag>_* are the files read below
+SEEDS = (0, 1, 2)               # SURVEY 8d / BASELINE.md: the repeats rotate these seeds
+STREAM_GAMES = 1 << 22          # the step API's streaming leg
 SIDE_LOCK_STEPS_CAP = 7680      # side legs: at most this many lock-steps per timed region
 MIN_WARMUP_LOCK_STEPS = 49152   # the headline's untimed warm-up lasts at least this long (see main)
 
@@ -96,10 +104,11 @@ def describe_mode(plan):
     if plan["eager_launches"]:
         how += " + %d eager launch(es)" % plan["eager_launches"]
     if c >= 2:
+        from tarok_amd import karte
         return ("tarok_krog_random: %d card(s) of every game per kernel launch (4 = one trick, the reference's krog); "
                 "action, observation, done, scores written to HBM for every card; %s; finished games' successors (dealt "
-                "seven games ahead by the refill workgroups of the previous launch) are swapped in inside the same launch"
-                % (c, how))
+                "%d games ahead by the refill workgroups of the previous launch) are swapped in inside the same launch"
+                % (c, how, karte.GAMES_AHEAD))
     if c == 1:
         return "tarok_step_random: one card of every game per launch, policy in-kernel; " + how
     return "tarok_policy_random + tarok_step: two launches per lock-step (what an external policy drives); " + how
@@ -208,14 +217,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     n = args.games
     offset, _ = sharding.weak_shard(n, rank)
-    env = TarokVecEnv(n, device=local_rank, seed=0, mix=K.MIX_ALL, game_offset=offset)
+    env = TarokVecEnv(n, device=local_rank, seed=SEEDS[0], mix=K.MIX_ALL, game_offset=offset)
     sha = kernel_src_sha()
     errors = []
 
-    def run(plan):
-        env.run_random(plan["lock_steps"], cards_per_launch=plan["cards"], graph_chunk=plan["graph_chunk"], auto_reset=True)
+    def run(plan, e=None):
+        (e or env).run_random(plan["lock_steps"], cards_per_launch=plan["cards"], graph_chunk=plan["graph_chunk"], auto_reset=True)
 
-    def timed(plan, events=None):
+    def timed(plan, events=None, e=None):
         """barrier + synchronize, the plan's launches, synchronize + barrier; MAX over ranks of the wall time.
         events: (ev0, ev1, stream) recorded on the launch stream around the same launches."""
         sharding.barrier()
@@ -223,7 +232,7 @@ def main():
         t0 = time.perf_counter()
         if events:
             events[0].record(events[2])
-        run(plan)
+        run(plan, e)
         if events:
             events[1].record(events[2])
         torch.cuda.synchronize(dev)
@@ -231,13 +240,13 @@ def main():
         dt = time.perf_counter() - t0
         return sharding.max_over_ranks([dt])[0]
 
-    def leg(cards, passes):
+    def leg(cards, passes, e=None):
         """A side leg: reset, warm up (graph capture untimed), one timed region.  -> (plan, seconds)"""
         chunk = min(args.graph_chunk, 1536)          # (graphs of at most 1,536 small launches)
         plan = plan_region(passes, cards, chunk)
-        env.reset(episode=0)
-        run(plan_region(min(passes, 2 * plan["launches_per_graph"]), cards, chunk, plan["launches_per_graph"]))
-        return plan, timed(plan)
+        (e or env).reset(episode=0)
+        run(plan_region(min(passes, 2 * plan["launches_per_graph"]), cards, chunk, plan["launches_per_graph"]), e)
+        return plan, timed(plan, None, e)
 
     # ---- headline: --steps launches of tarok_krog_random(cards); per card: legal mask -> uniform random
     # legal card -> apply -> (4th card) trick winner / scoring / auto-reset swap -> next observation
@@ -258,8 +267,23 @@ def main():
     ev_ms = ev[0].elapsed_time(ev[1])
     env_steps = n * plan["lock_steps"] * world_size
     value = env_steps / dt
-    # 5 repeats, median (min-max).  `value` stays the first region (the contract's one).
-    spread = [value] + [env_steps / timed(plan) for _ in range(max(0, args.repeats - 1))]
+    # 5 repeats over the seeds {0, 1, 2}, median (min-max).  `value` stays the first region (seed 0: the
+    # contract's one); every further seed gets its own env, warmed up and graph-captured like the first
+    seed_envs = {SEEDS[0]: env}
+    spread, per_seed = [value], {str(SEEDS[0]): [value]}
+    for k in range(1, max(1, args.repeats)):
+        sd = SEEDS[k % len(SEEDS)]
+        if sd not in seed_envs:
+            e2 = TarokVecEnv(n, device=local_rank, seed=sd, mix=K.MIX_ALL, game_offset=offset)
+            e2.reset(episode=0)
+            run(wplan, e2)
+            seed_envs[sd] = e2
+        v = env_steps / timed(plan, None, seed_envs[sd])
+        spread.append(v)
+        per_seed.setdefault(str(sd), []).append(v)
+    for sd, e2 in seed_envs.items():
+        if e2 is not env:
+            e2.close()
     ep, ss = env.counters()
 
     out = {
@@ -281,12 +305,14 @@ def main():
                    "games_per_gpu": n, "mode": describe_mode(plan), "cards_per_launch": cards, "launch_plan": plan,
                    "parallelism": "games sharded %d-way by global game index, no collective in the env path" % world_size},
         "episodes_finished_rank0": int(ep.sum()),
-        "repeats": {"n": len(spread), "median": sorted(spread)[len(spread) // 2], "min": min(spread), "max": max(spread)},
+        "repeats": {"n": len(spread), "median": sorted(spread)[len(spread) // 2], "min": min(spread), "max": max(spread),
+                    "seeds": [SEEDS[k % len(SEEDS)] for k in range(len(spread))], "per_seed": per_seed,
+                    "note": "region k runs seed k mod 3 (its own env and graph); `value` is region 0"},
         "kernel_src_sha": sha,
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (k_play<true>): HIP events on the launch stream around the
+        # ---- roofline of the dominant kernel (k_play_wide): HIP events on the launch stream around the
         # timed region; launch duration = region time / launches (every launch gap is charged to the
         # kernel -> a lower bound on its bandwidth).
         k_us = ev_ms * 1e3 / plan["launches"]
@@ -298,7 +324,8 @@ def main():
         # from inside the process): FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py
         pmc, prov = load_profile("%s_pmc_fetch_write_%d.json" % (PROFILE_TAG, n), sha)
         traffic = pmc.get("k_play_traffic_bytes_per_launch_cards%d" % cards) if pmc else None
-        roof = {"bound": "hbm", "kernel": "k_play<true> (%s)" % ("tarok_krog_random" if cards > 1 else "tarok_step_random"),
+        roof = {"bound": "instruction issue (see issue_roofline); the HBM side is reported here: achieved / peak = hbm_frac" if cards > 1 else "hbm",
+                "kernel": "k_play_wide (tarok_krog_random)" if cards > 1 else "k_step<true> (tarok_step_random)",
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_us": k_us, "steps_per_launch": n * plan["lock_steps_per_launch"],
                 "traffic": traffic, "traffic_provenance": prov, "algorithmic": algo}
         if cards > 1 and traffic:
@@ -312,7 +339,7 @@ def main():
                         achieved=algo["achieved"])
             if cards > 1:
                 algo["note"] = "the state stays in registers for the cards of a launch: real traffic is lower than this figure"
-        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["frac"] = roof["hbm_frac"] = roof["achieved"] / HBM_PEAK_GBS
         roof["note"] = ("at %d games the per-GPU state (%.0f MB with the next-game lines) is cache resident and there are only "
                         "%d play waves for 1,024 SIMDs: the launch is bound by instruction issue, not by HBM (issue_roofline; "
                         "DESIGN.md has the N sweep)" % (n, n * 520 / 1e6, (n + 63) // 64))
@@ -370,7 +397,7 @@ def main():
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
         if rank == 0:
             ach = ALGO_BYTES_PER_STEP * n / (us0 * 1e-6) / 1e9
-            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_play<false> (tarok_step) behind k_policy (tarok_policy_random)",
+            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step) behind k_policy (tarok_policy_random)",
                                         "accounting": "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step" % n,
                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                         "us_per_lock_step": us0, "traffic": None,
@@ -380,8 +407,51 @@ def main():
             # measured HBM bytes of the two kernels of a lock-step (PMC passes of the all-modes command)
             pma, pma_prov = load_profile("%s_pmc_fetch_write_all_modes_%d.json" % (PROFILE_TAG, n), sha)
             if pma and "k_step_traffic_bytes_per_launch" in pma:
-                out["roofline_step_api"]["traffic"] = pma["k_step_traffic_bytes_per_launch"] + pma.get("k_policy_traffic_bytes_per_launch", 0)
-                out["roofline_step_api"]["traffic_provenance"] = pma_prov
+                tr = pma["k_step_traffic_bytes_per_launch"] + pma.get("k_policy_traffic_bytes_per_launch", 0)
+                out["roofline_step_api"].update(traffic=tr, traffic_over_algorithmic=tr / float(ALGO_BYTES_PER_STEP * n),
+                                                traffic_provenance=pma_prov)
+        # (a0) the same path where it streams: 4 M games (the state no longer fits the caches; 54 B/step against 8 TB/s
+        # is a meaningful fraction here).  Its own env; skipped when the batch is not the default (N sweeps).
+        if n == 65536 and world_size == 1:
+            try:
+                es = TarokVecEnv(STREAM_GAMES, device=local_rank, seed=SEEDS[0], mix=K.MIX_ALL)
+                stream = {}
+                for c_, name in ((0, "policy_plus_step"), (1, "step_random")):
+                    ps_, dts = leg(c_, 384, es)
+                    us = dts / ps_["lock_steps"] * 1e6
+                    ach = ALGO_BYTES_PER_STEP * STREAM_GAMES / (us * 1e-6) / 1e9
+                    stream[name] = {"us_per_lock_step": us, "env_steps_per_s": STREAM_GAMES / (us * 1e-6),
+                                    "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+                es.close()
+                stream["games"] = STREAM_GAMES
+                stream["accounting"] = "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step, against 8 TB/s" % STREAM_GAMES
+                led, led_prov = load_profile("%s_step_ledger.json" % PROFILE_TAG, sha)
+                if led:
+                    stream["traffic_bytes_per_step"] = led.get("two_kernel_bytes_per_step")
+                    stream["traffic_over_algorithmic"] = led.get("two_kernel_bytes_per_step", 0) / float(ALGO_BYTES_PER_STEP)
+                    stream["traffic_provenance"] = led_prov
+                if rank == 0:
+                    out["roofline_step_api"]["streaming"] = stream
+            except Exception as ex:
+                errors.append("step_api_streaming: " + repr(ex))
+                print("bench.py: the streaming step-API leg FAILED: %r" % (ex,), file=sys.stderr)
+        # (a00) BASELINE configs[1]: 4,096 Tri / Dve / Ena games — the headline mode and the step API
+        try:
+            n2 = 4096
+            e2 = TarokVecEnv(n2, device=local_rank, seed=SEEDS[0], mix=K.MIX_NAVADNA3, game_offset=sharding.weak_shard(n2, rank)[0])
+            pa, dta2 = leg(cards, max(1, side_steps // max(1, cards)), e2)
+            pb, dtb2 = leg(0, side_steps, e2)
+            out["config2"] = {"workload": "configs[1]: %d parallel Tri / Dve / Ena games per GPU, uniform random policy, auto-reset" % n2,
+                              "headline_mode": {"value": n2 * pa["lock_steps"] * world_size / dta2, "unit": "env steps/s",
+                                                "us_per_lock_step": dta2 / pa["lock_steps"] * 1e6, "cards_per_launch": cards},
+                              "step_api": {"value": n2 * pb["lock_steps"] * world_size / dtb2, "unit": "env steps/s",
+                                           "us_per_lock_step": dtb2 / pb["lock_steps"] * 1e6},
+                              "note": "64 play waves for 1,024 SIMDs: launch-latency bound in both modes; bit-exactness of this "
+                                      "configuration is pinned by the reference's digest (test_fused_rollout_digests_match_reference)"}
+            e2.close()
+        except Exception as ex:
+            errors.append("config2: " + repr(ex))
+            print("bench.py: the config-2 leg FAILED: %r" % (ex,), file=sys.stderr)
         # (a') one trick per launch (tarok_krog_random, 4 cards)
         if cards != 4:
             p4, dt4 = leg(4, max(1, side_steps // 4))
@@ -424,12 +494,16 @@ def main():
             sp.iterate(T=48, epochs=1, minibatches=8)
             st = sp.iterate(T=48, epochs=1, minibatches=8)
             tro = sharding.max_over_ranks([st["rollout_s"], st["update_s"]])
-            out["selfplay_ppo"] = {"rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_us_per_lock_step": tro[0] / 48 * 1e6,
+            out["selfplay_ppo"] = {"iteration_env_steps_per_s": n * 48 * world_size / (tro[0] + tro[1]),
+                                   "rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_us_per_lock_step": tro[0] / 48 * 1e6,
                                    "update_ms": tro[1] * 1e3, "minibatches": 8, "allreduce_bytes_per_minibatch": st["allreduce_bytes"],
                                    "policy": "MLP 256-256-256-64 (54 card logits + value), bf16 MFMA", "loss": st["loss"],
-                                   "note": "env steps/s including the policy: per lock-step one tarok_policy_step launch "
-                                           "(features -> MLP -> masked sample -> env step), graph replayed; update = PPO-style, "
-                                           "tarok_ppo_loss + torch GEMMs"}
+                                   "learner": "fused (tarok_learn_*)" if getattr(sp, "fused_learner", False) else "torch",
+                                   "note": "iteration = one rollout of 48 lock-steps + one update over its %d samples (1 epoch, 8 "
+                                           "minibatches): the end-to-end figure.  Rollout: per lock-step one tarok_policy_step launch "
+                                           "(features -> MLP -> masked sample -> env step), graph replayed.  Update: returns kernel; per "
+                                           "minibatch forward + loss + backward chain in one MFMA kernel, the three weight gradients as "
+                                           "one split-K launch, one flat gradient all-reduce, clip + Adam in one launch" % (n * 48)}
             del sp
         except Exception as ex:
             out["selfplay_ppo"] = {"error": repr(ex)}

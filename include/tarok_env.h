@@ -37,6 +37,7 @@ extern "C" {
 
 #define TAROK_ABI_VERSION 3
 #define TAROK_MAX_CARDS_PER_LAUNCH 192 /* tarok_krog_random / tarok_run_random: cards of every game per launch */
+#define TAROK_GAMES_AHEAD 14           /* games every slot keeps dealt ahead for TAROK_AUTO_RESET (tarok_prefetch)  */
 
 #define TAROK_OK 0
 #define TAROK_EINVAL (-1) /* bad argument                                  */
@@ -325,6 +326,71 @@ int tarok_ppo_loss(tarok_env *env, int64_t n_samples, const void *out_bf16, cons
                    const int64_t *action, const float *logp_old, const float *advantage, const float *ret,
                    const float *weight, float clip, float vf_coef, float ent_coef, const float *inv_weight_sum,
                    void *dout_bf16, float *partial_out, void *stream);
+
+/* The reference agent's training targets in its own form (Nevronski_igralec.rezultat_stiha +
+ * rezultat_igre, Igralec.py:387-446) for a recorded rollout of T lock-steps, T a multiple of 4, started on a trick
+ * boundary (trick b = rows 4b .. 4b+3 of every slot, through the auto-resets):
+ *   obs_before [T,N] u64   the observation word each card was chosen on (legal mask = `mozne`, seat to move)
+ *   action [T,N] u8, trick [T,N] u16 (trick_out), done [T,N] u8, reward [T,N,4] i16 with TAROK_REWARD_REF
+ *   next_q [T,N] f32 or NULL  the agent's own next_Q_max at each decision (Igralec.py:351); NULL = 0
+ *   dy_out [T/4,N,4,54] f32: per (trick, game, seat) -70 on the cards that were not legal (:392-393), on the card
+ *           played +/- Roka.vrednost_stiha(trick) by who took it (:412-416) + final_reward_factor * next_max (:441),
+ *           next_max = next_q at the seat's next decision (:417-418) or the final reward on the game's last trick (:439)
+ *   meta_out [T/4,N,4] u8: bit 0 row valid (the seat played in a completed trick), bit 1 last transition of its
+ *           game, bit 2 the seat's next decision lies beyond the rollout (next_max taken as 0).
+ * Parity unpinned for the assembly (no reference fixture; Igralec.py cannot be imported), pinned for its inputs. */
+int tarok_targets_ref(tarok_env *env, int T, const uint64_t *obs_before, const uint8_t *action, const uint16_t *trick,
+                      const uint8_t *done, const int16_t *reward, const float *next_q, float final_reward_factor,
+                      float *dy_out, uint8_t *meta_out, void *stream);
+
+/* ---- The learner's update of the policy above as a few fused launches (build-owned, like the policy itself:
+ * the reference's learner is a double-Q LSTM agent under pytorch-lightning, Igralec.py:545-714).  The network
+ * 256-256-256-64 lives in ONE flat f32 vector of TAROK_MLP_PARAMS entries, in torch.nn.Linear layouts:
+ * W1 [256,256] | b1 [256] | W2 [256,256] | b2 [256] | W3 [64,256] | b3 [64]  (offsets TAROK_MLP_*). */
+#define TAROK_MLP_W1 0
+#define TAROK_MLP_B1 65536
+#define TAROK_MLP_W2 65792
+#define TAROK_MLP_B2 131328
+#define TAROK_MLP_W3 131584
+#define TAROK_MLP_B3 147968
+#define TAROK_MLP_PARAMS 148032
+
+/* Returns of a rollout of T lock-steps (rows [T,N] as written by tarok_policy_step): every card is credited with
+ * its seat's final score of the game it belongs to, times reward_scale.
+ *   rec_out [T,N,4] f32: {log-probability at play time, return, value at play time, bits: card | known << 8}
+ *           (known = that game ended inside the rollout; other samples carry weight 0 in the update)
+ *   stats_out [4] f32: {mean, 1 / std of the advantages (return - value) over the known samples, known fraction, 0}
+ *   scratch [ceil(N/256),4] f32. */
+int tarok_learn_returns(tarok_env *env, int T, const uint8_t *done, const int16_t *reward, const uint64_t *obs,
+                        const float *logp, const float *value, const uint8_t *action, float reward_scale,
+                        float *rec_out, float *stats_out, float *scratch, void *stream);
+
+/* Forward, loss and backward chain of one minibatch of B samples (sample j = row index[j] of feature_words [M,4] /
+ * rec [M,4]; index NULL: row j): feature gather + expansion -> layers 1-3 -> the loss of tarok_ppo_loss (advantage
+ * = (return - value - stats[0]) * stats[1], weight = known) -> dH2, dH1.  Weights: the bf16 fragment-order copies
+ * tarok_learn_adam writes (w3t / w2t: of the transposes), biases: pointers into the flat vector.
+ *   H1 / H2 / dH2 / dH1 [B,256] bf16, dOut [B,64] bf16 (unscaled: weight w, not w / sum w) for tarok_learn_dw;
+ *   scratch [ceil(B/128),4] f32; terms_out [4] f32 = {policy loss, value loss, entropy (weighted means),
+ *   1 / max(sum w, 1)}; running [4] f32 or NULL: += {the three terms, 1}. */
+int tarok_learn_chain(tarok_env *env, int64_t B, const uint64_t *feature_words, const int64_t *index, const float *rec,
+                      const float *stats, float clip, float vf_coef, float ent_coef, const void *w1, const float *b1,
+                      const void *w2, const float *b2, const void *w3, const float *b3, const void *w3t, const void *w2t,
+                      void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
+                      float *running, void *stream);
+
+/* The weight and bias gradients of that minibatch: grad_out [TAROK_MLP_PARAMS] f32 = terms[3] * (dH^T H per layer,
+ * column sums of dH), in the flat parameter order.  workspace: tarok_learn_workspace_bytes(env) bytes. */
+int64_t tarok_learn_workspace_bytes(tarok_env *env);
+int tarok_learn_dw(tarok_env *env, int64_t B, const uint64_t *feature_words, const int64_t *index, const void *H1,
+                   const void *H2, const void *dOut, const void *dH2, const void *dH1, const float *terms,
+                   void *workspace, float *grad_out, void *stream);
+
+/* Gradient-norm clip (max_norm <= 0: none) + Adam (torch.optim.Adam semantics) on the flat vectors, then the
+ * kernels' bf16 fragment-order weight copies (any may be NULL).  step: device counter, incremented.
+ * apply = 0: only rebuild the copies from param.  gnorm_out [1] f32 or NULL. */
+int tarok_learn_adam(tarok_env *env, float *param, const float *grad, float *m, float *v, int32_t *step, float lr,
+                     float beta1, float beta2, float eps, float max_norm, void *w1, void *w2, void *w3, void *w3t,
+                     void *w2t, float *gnorm_out, int apply, void *stream);
 
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */

@@ -127,6 +127,41 @@ def rezultat_igre_st_tock(st_tock, tip, is_declarer, cards_in_hand):
     return st_tock
 
 
+def rezultat_stiha_dy(mozne_vec, igrana_karta, vrednost_stiha, sem_pobral, tip_igre_dict=None):
+    """Igralec.py:387-419, the training target of ONE transition before the game's end is folded in:
+    `dy` = -70 on every card that was not legal at the player's decision (:392-393; `self.stanje[id][-1]` is
+    `mozne_vec`), and on the card played the trick's value (Roka.vrednost_stiha of the 4 — Klop: 5 — cards)
+    with the sign of `sem_pobral` (:412-416).  The Klop branch (:394-398) and the Berac branch (:399-409)
+    are DEAD: they compare `self.tip_igre`, which is a dict keyed by game id (:200,258), with a string, so the
+    comparison is False for every contract and the `else` of :411 always runs — kept here as the reference has
+    them, with the same comparison (tip_igre_dict: the dict; any value gives the same result)."""
+    dy = np.zeros(54)
+    dy[np.asarray(mozne_vec) == 0] = -70
+    tip_igre = {} if tip_igre_dict is None else tip_igre_dict
+    if tip_igre == "Klop":                                  # never true (:394)
+        dy[igrana_karta] = -vrednost_stiha if sem_pobral else vrednost_stiha
+    elif tip_igre == "Berac":                               # never true (:399)
+        dy[igrana_karta] = -1 if sem_pobral else 1
+    else:
+        dy[igrana_karta] = vrednost_stiha if sem_pobral else -vrednost_stiha
+    return dy
+
+
+def rezultat_igre_dy(transitions, st_tock, final_reword_factor):
+    """Igralec.py:417-418,439-442.  `transitions` = the player's [dy, igrana_karta, next_Q_max] in play order,
+    next_Q_max = the value the agent stored at its NEXT decision (:351: the predicted Q of the card its network
+    ranks first), which rezultat_stiha writes into the previous transition (:417-418); the last transition gets
+    the final reward instead (:439: st_tock after the Berac rule of :434-437, rezultat_igre_st_tock).  Then every
+    target's played card gains next_max * final_reword_factor (:441).  Returns the list of dy."""
+    out = []
+    for k, (dy, karta, next_q) in enumerate(transitions):
+        next_max = st_tock if k == len(transitions) - 1 else next_q
+        dy = np.array(dy, dtype=np.float64)
+        dy[karta] = dy[karta] + next_max * final_reword_factor
+        out.append(dy)
+    return out
+
+
 # ---------------------------------------------------------------------------
 # helpers for the tests: the reference's history of a recorded game, and the device record layout
 # ---------------------------------------------------------------------------

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "tarok_env.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "tarok_device.h"), os.path.join(HERE, "csrc", "deal_network.inc"),
+        os.path.join(HERE, "csrc", "tarok_learner.inc"),
         os.path.join(ROOT, "include", "tarok_env.h")]
 LIB_PATH = os.environ.get("TAROK_LIB") or os.path.join(HERE, "libtarokenv.so")   # TAROK_LIB: A/B diagnostics only
 ARCH = "gfx950"
@@ -19,6 +20,7 @@ SYMBOLS = [
     "tarok_create", "tarok_destroy", "tarok_num_games", "tarok_set_option", "tarok_reset", "tarok_exchange",
     "tarok_legal_actions", "tarok_step", "tarok_prefetch", "tarok_policy_random", "tarok_step_random",
     "tarok_run_random", "tarok_krog_random", "tarok_rollout_random", "tarok_get_state", "tarok_set_state", "tarok_get_counters", "tarok_debug_stamps", "tarok_observe", "tarok_sample_policy", "tarok_policy_mlp", "tarok_policy_step", "tarok_expand_features", "tarok_ppo_loss",
+    "tarok_targets_ref", "tarok_learn_returns", "tarok_learn_chain", "tarok_learn_workspace_bytes", "tarok_learn_dw", "tarok_learn_adam",
     "tarok_observe_ref", "tarok_observe_exchange_ref", "tarok_observe_hands_ref", "tarok_get_history", "tarok_set_history",
 ]
 
@@ -133,6 +135,14 @@ def lib():
     L.tarok_expand_features.restype = i32; L.tarok_expand_features.argtypes = [vp, i64, vp, vp, vp, vp]
     f32 = C.c_float
     L.tarok_ppo_loss.restype = i32; L.tarok_ppo_loss.argtypes = [vp, i64] + [vp] * 7 + [f32] * 3 + [vp] * 4
+    if hasattr(L, "tarok_targets_ref"):
+        L.tarok_targets_ref.restype = i32; L.tarok_targets_ref.argtypes = [vp, i32] + [vp] * 6 + [f32] + [vp] * 3
+    if hasattr(L, "tarok_learn_chain"):
+        L.tarok_learn_returns.restype = i32; L.tarok_learn_returns.argtypes = [vp, i32] + [vp] * 6 + [f32] + [vp] * 4
+        L.tarok_learn_chain.restype = i32; L.tarok_learn_chain.argtypes = [vp, i64] + [vp] * 4 + [f32] * 3 + [vp] * 17
+        L.tarok_learn_workspace_bytes.restype = i64; L.tarok_learn_workspace_bytes.argtypes = [vp]
+        L.tarok_learn_dw.restype = i32; L.tarok_learn_dw.argtypes = [vp, i64] + [vp] * 11
+        L.tarok_learn_adam.restype = i32; L.tarok_learn_adam.argtypes = [vp] * 6 + [f32] * 5 + [vp] * 6 + [i32, vp]
     L.tarok_observe_ref.restype = i32; L.tarok_observe_ref.argtypes = [vp, vp, vp, vp]
     L.tarok_observe_exchange_ref.restype = i32; L.tarok_observe_exchange_ref.argtypes = [vp, vp, vp]
     L.tarok_observe_hands_ref.restype = i32; L.tarok_observe_hands_ref.argtypes = [vp, vp, vp]

@@ -43,7 +43,7 @@
 #define TK_RC(group, par) ((((size_t)(group)) * 2 + (par)) * 32)
 
 #ifndef TK_AHEAD
-#define TK_AHEAD 14                 // next-game lines per slot (<= 15: epar and cprev are 4 bits each)
+#define TK_AHEAD TAROK_GAMES_AHEAD  // next-game lines per slot (<= 15: epar and cprev are 4 bits each)
 #endif
 #define TK_LINE(episode) ((u32)(episode) % (u32)TK_AHEAD)
 #define TK_FINQ 128                 // entries of a play wave's finished-games ring (a power of two >= 128)
@@ -107,6 +107,7 @@ struct tarok_env {
     u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
+    int n_cus;               // compute units of the device (k_learn_dw's grid), 0 = not asked yet
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -1932,6 +1933,85 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
 
 #endif  // TK_BLOCK == 256
 
+// ---------------------------------------------------------------------------
+// The reference agent's transition targets in its own form: what Nevronski_igralec.rezultat_stiha
+// builds per trick and rezultat_igre completes (Igralec.py:387-446), for every (trick, game, seat) of a recorded
+// rollout of whole tricks:  dy[54] = -70 on the cards that were not legal at the seat's decision (:392-393), on the
+// card it played +Roka.vrednost_stiha(trick) if it took the trick, else minus that (:412-416: every contract runs
+// this branch, the Klop / Berac branches of :394-409 compare a dict with a string), plus final_reword_factor times
+// next_max (:441), where next_max is the agent's own estimate at its next decision (:351,417-418; `next_q`, the
+// caller's: NULL = 0) or, on the game's last trick, the final reward (:439, the rewards of TAROK_REWARD_REF).
+// Rows [T,N] as the step kernels wrote them; T a multiple of 4 and the rollout starts on a trick boundary (games are
+// whole tricks long, so every slot stays trick-aligned through the auto-resets): trick b = rows 4b .. 4b+3.
+// Parity unpinned for this assembly (the reference holds no fixture and Igralec.py cannot be imported); its inputs —
+// legal masks, cards, trick values and winners, final scores — are pinned by the reference's recorded runs.
+// Workgroup = 64 slots x 4 seats: one thread per (slot, seat) builds its row's description, then the 256 threads
+// write the 64 x 4 x 54 floats of the workgroup as full lines.
+#define TG_SLOTS 64
+__global__ __launch_bounds__(256) void k_targets_ref(int64_t n, int T, const u64 *__restrict__ obs_before, const uint8_t *__restrict__ action,
+                                                    const uint16_t *__restrict__ trick, const uint8_t *__restrict__ done,
+                                                    const int16_t *__restrict__ reward, const float *__restrict__ next_q, float factor,
+                                                    float4 *__restrict__ dy, uint8_t *__restrict__ meta) {
+    __shared__ uint2 mask_s[256];
+    __shared__ float val_s[256];
+    __shared__ u32 card_s[256];
+    const u32 tid = threadIdx.x, b = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * TG_SLOTS, i = i0 + (tid >> 2);
+    const u32 s = tid & 3;
+    u64 legal = TK_DECK;                                      // (rows without a decision: all zeros)
+    u32 card = 255, flags = 0;
+    float val = 0.f;
+    if (i < n) {
+        int found = -1;
+        for (int k = 0; k < 4; k++) {
+            u64 ob = obs_before[(int64_t)(4 * b + k) * n + i];
+            bool mine = ((u32)(ob >> TAROK_OBS_SEAT_SHIFT) & 3u) == s && action[(int64_t)(4 * b + k) * n + i] < 54 &&
+                        !(ob & TAROK_OBS_DONE & 0) && found < 0;
+            if (mine) { found = k; legal = ob & TAROK_OBS_MASK; card = action[(int64_t)(4 * b + k) * n + i]; }
+        }
+        int64_t last = (int64_t)(4 * b + 3) * n + i;
+        u32 tw = trick[last];
+        if (found >= 0 && (tw & 0x8000u)) {
+            flags = 1;
+            float tv = (float)((tw >> 4) & 0x7FFu);
+            val = ((tw & 3u) == s) ? tv : -tv;                // sem_pobral (Klop.py:76-77, Navadna_igra.py:138-139)
+            float next_max = 0.f;
+            if (done[last]) { next_max = (float)reward[last * 4 + s]; flags |= 2; }
+            else if ((int)(4 * b + 7) < T) {
+                int nk = -1;
+                for (int k = 0; k < 4; k++) {
+                    u64 ob = obs_before[(int64_t)(4 * b + 4 + k) * n + i];
+                    if (((u32)(ob >> TAROK_OBS_SEAT_SHIFT) & 3u) == s && nk < 0) nk = k;
+                }
+                if (nk >= 0) next_max = next_q ? next_q[(int64_t)(4 * b + 4 + nk) * n + i] : 0.f;
+                else flags |= 4;
+            } else flags |= 4;                                // the seat's next decision lies beyond the rollout
+            val += factor * next_max;
+        } else { legal = TK_DECK; card = 255; }
+        meta[((int64_t)b * n + i) * 4 + s] = (uint8_t)flags;
+    }
+    mask_s[tid] = make_uint2(TK_LO(legal), TK_HI(legal));
+    val_s[tid] = val;
+    card_s[tid] = card;
+    __syncthreads();
+    int64_t slots = n - i0 < TG_SLOTS ? n - i0 : TG_SLOTS;
+    u32 quads = (u32)(slots * 4 * 54 / 4);                    // float4 pieces of this workgroup's rows
+    float4 *out = dy + ((int64_t)b * n + i0) * 54;            // (row (b, i, seat) starts at float ((b n + i) 4 + seat) 54)
+    for (u32 e4 = tid; e4 < quads; e4 += 256) {
+        float v[4];
+#pragma unroll
+        for (u32 k = 0; k < 4; k++) {
+            u32 e = 4 * e4 + k, row = e / 54, c = e - 54 * row;
+            uint2 m = mask_s[row];
+            u32 bit = c < 32 ? (m.x >> c) & 1u : (m.y >> (c - 32)) & 1u;
+            v[k] = c == card_s[row] ? val_s[row] : (bit ? 0.f : -70.f);
+        }
+        out[e4] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+#include "tarok_learner.inc"
+
 __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
                                                       int4 *__restrict__ score_sum) {
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
@@ -2407,6 +2487,118 @@ int tarok_ppo_loss(tarok_env *e, int64_t n_samples, const void *out_bf16, const 
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
+
+int tarok_targets_ref(tarok_env *e, int T, const uint64_t *obs_before, const uint8_t *action, const uint16_t *trick,
+                      const uint8_t *done, const int16_t *reward, const float *next_q, float final_reward_factor, float *dy_out,
+                      uint8_t *meta_out, void *stream) {
+    if (!e || T < 4 || (T & 3) || !obs_before || !action || !trick || !done || !reward || !dy_out || !meta_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    dim3 grid((unsigned)((e->n + TG_SLOTS - 1) / TG_SLOTS), (unsigned)(T / 4));
+    hipLaunchKernelGGL(k_targets_ref, grid, dim3(256), 0, (hipStream_t)stream, e->n, T, (const u64 *)obs_before, action, trick, done,
+                       reward, next_q, final_reward_factor, (float4 *)dy_out, meta_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+#if TK_BLOCK == 256
+int tarok_learn_returns(tarok_env *e, int T, const uint8_t *done, const int16_t *reward, const uint64_t *obs, const float *logp,
+                        const float *value, const uint8_t *action, float reward_scale, float *rec_out, float *stats_out,
+                        float *scratch, void *stream) {
+    if (!e || T < 1 || !done || !reward || !obs || !logp || !value || !action || !rec_out || !stats_out || !scratch) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    dim3 grid = grid_for(e->n);
+    hipLaunchKernelGGL(k_returns, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, T, done, reward, (const u64 *)obs, logp, value,
+                       action, reward_scale, (float4 *)rec_out, (float4 *)scratch);
+    hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(TK_BLOCK), 0, (hipStream_t)stream, (int)grid.x, (int64_t)T * e->n,
+                       (const float4 *)scratch, (float4 *)stats_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, const int64_t *index, const float *rec,
+                      const float *stats, float clip, float vf_coef, float ent_coef, const void *w1, const float *b1,
+                      const void *w2, const float *b2, const void *w3, const float *b3, const void *w3t, const void *w2t,
+                      void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
+                      float *running, void *stream) {
+    if (!e || B < 1 || !feature_words || !rec || !stats || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w3t || !w2t || !H1 || !H2 ||
+        !dOut || !dH2 || !dH1 || !scratch || !terms_out)
+        return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    LearnArgs a;
+    a.B = B; a.words = (const u64 *)feature_words; a.index = index; a.rec = (const float4 *)rec; a.stats = (const float4 *)stats;
+    a.clip = clip; a.vf_coef = vf_coef; a.ent_coef = ent_coef;
+    a.w1 = (const __bf16 *)w1; a.w2 = (const __bf16 *)w2; a.w3 = (const __bf16 *)w3; a.w3t = (const __bf16 *)w3t; a.w2t = (const __bf16 *)w2t;
+    a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.H1 = (uint4 *)H1; a.H2 = (uint4 *)H2; a.dH2 = (uint4 *)dH2; a.dH1 = (uint4 *)dH1; a.dOut = (uint2 *)dOut;
+    a.part = (float4 *)scratch;
+    unsigned blocks = (unsigned)((B + LN_M - 1) / LN_M);
+    hipLaunchKernelGGL(k_learn_chain, dim3(blocks), dim3(TK_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_learn_terms, dim3(1), dim3(TK_BLOCK), 0, (hipStream_t)stream, (int)blocks, (const float4 *)scratch,
+                       (float4 *)terms_out, (float4 *)running);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+// chunks per layer of k_learn_dw: one workgroup per CU in all, shared out by the bytes a sample costs each layer
+// (layer 2: H1 + dH2 = 1024, layer 1: feature words + dH1 = 544, layer 3: H2 + dOut = 640: the kernel is HBM bound)
+static inline void learn_chunks(tarok_env *e, u32 &c2, u32 &c1, u32 &c3) {
+    if (!e->n_cus) {
+        hipDeviceProp_t pr;
+        e->n_cus = hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    u32 total = (u32)e->n_cus < 8 ? 8 : (u32)e->n_cus;
+    c2 = total * 1024 / 2208; c1 = total * 544 / 2208; c3 = total - c2 - c1;
+}
+
+int64_t tarok_learn_workspace_bytes(tarok_env *e) {
+    if (!e) return 0;
+    u32 c2, c1, c3;
+    learn_chunks(e, c2, c1, c3);
+    return (int64_t)sizeof(float) * ((int64_t)(c2 + c1) * 65792 + (int64_t)c3 * 16448);
+}
+
+int tarok_learn_dw(tarok_env *e, int64_t B, const uint64_t *feature_words, const int64_t *index, const void *H1, const void *H2,
+                   const void *dOut, const void *dH2, const void *dH1, const float *terms, void *workspace, float *grad_out,
+                   void *stream) {
+    if (!e || B < 1 || !feature_words || !H1 || !H2 || !dOut || !dH2 || !dH1 || !terms || !workspace || !grad_out) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    u32 c2, c1, c3;
+    learn_chunks(e, c2, c1, c3);
+    hipLaunchKernelGGL(k_learn_dw, dim3(c2 + c1 + c3), dim3(TK_BLOCK), 0, (hipStream_t)stream, B, c2, c1, c3, (const u64 *)feature_words,
+                       index, (const uint4 *)H1, (const uint4 *)H2, (const uint4 *)dOut, (const uint4 *)dH2, (const uint4 *)dH1,
+                       (float *)workspace);
+    hipLaunchKernelGGL(k_learn_reduce, dim3((LN_P + TK_BLOCK - 1) / TK_BLOCK), dim3(TK_BLOCK), 0, (hipStream_t)stream, c2, c1, c3,
+                       (const float *)workspace, (const float4 *)terms, grad_out);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+
+int tarok_learn_adam(tarok_env *e, float *param, const float *grad, float *m, float *v, int32_t *step, float lr, float beta1,
+                     float beta2, float eps, float max_norm, void *w1, void *w2, void *w3, void *w3t, void *w2t, float *gnorm_out,
+                     int apply, void *stream) {
+    if (!e || !param || (apply && (!grad || !m || !v || !step))) return TAROK_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    AdamArgs a;
+    a.param = param; a.grad = const_cast<float *>(grad); a.m = m; a.v = v; a.step = step;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    a.w1 = (__bf16 *)w1; a.w2 = (__bf16 *)w2; a.w3 = (__bf16 *)w3; a.w3t = (__bf16 *)w3t; a.w2t = (__bf16 *)w2t;
+    a.gnorm = gnorm_out; a.apply = apply;
+    hipLaunchKernelGGL(k_learn_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return TAROK_OK;
+}
+#else
+int tarok_learn_returns(tarok_env *, int, const uint8_t *, const int16_t *, const uint64_t *, const float *, const float *, const uint8_t *,
+                        float, float *, float *, float *, void *) { return TAROK_EINVAL; }
+int tarok_learn_chain(tarok_env *, int64_t, const uint64_t *, const int64_t *, const float *, const float *, float, float, float,
+                      const void *, const float *, const void *, const float *, const void *, const float *, const void *, const void *,
+                      void *, void *, void *, void *, void *, float *, float *, float *, void *) { return TAROK_EINVAL; }
+int64_t tarok_learn_workspace_bytes(tarok_env *) { return 0; }
+int tarok_learn_dw(tarok_env *, int64_t, const uint64_t *, const int64_t *, const void *, const void *, const void *, const void *,
+                   const void *, const float *, void *, float *, void *) { return TAROK_EINVAL; }
+int tarok_learn_adam(tarok_env *, float *, const float *, float *, float *, int32_t *, float, float, float, float, float, void *, void *,
+                     void *, void *, void *, float *, int, void *) { return TAROK_EINVAL; }
+#endif
 
 int tarok_get_state(tarok_env *e, uint64_t *lanes_out, void *stream) {
     if (!e || !lanes_out) return TAROK_EINVAL;

@@ -389,6 +389,54 @@ class TarokVecEnv:
             terms = part.sum(0)[:3] * inv
         return terms, dout
 
+    def targets_ref(self, obs_before, action, trick, done, reward, next_q=None, factor=0.1):
+        """The reference agent's transition targets (tarok_targets_ref; Igralec.py:387-446) of a recorded rollout:
+        rows [T,N] (reward [T,N,4] recorded with reward_ref=True), T a multiple of 4 from a trick boundary.
+        Returns (dy [T/4,N,4,54] f32, meta [T/4,N,4] u8)."""
+        Tn = obs_before.shape[0]
+        with torch.cuda.device(self.device):
+            dy = torch.empty((Tn // 4, self.n, 4, 54), dtype=torch.float32, device=self.device)
+            meta = torch.empty((Tn // 4, self.n, 4), dtype=torch.uint8, device=self.device)
+            c = lambda t: None if t is None else t.contiguous()
+            _native.check(self.L.tarok_targets_ref(self._h, int(Tn), self._p(c(obs_before)), self._p(c(action)), self._p(c(trick)),
+                                                   self._p(c(done)), self._p(c(reward)), self._p(c(next_q)), float(factor),
+                                                   self._p(dy), self._p(meta), self._stream()))
+        return dy, meta
+
+    # ---- the fused learner (include/tarok_env.h tarok_learn_*; driven by tarok_amd.selfplay.SelfPlay.update_fused)
+    def learn_returns(self, T, done, reward, words, logp, val, act, reward_scale, rec, stats, scratch):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_learn_returns(self._h, int(T), self._p(done), self._p(reward), self._p(words), self._p(logp),
+                                                     self._p(val), self._p(act), float(reward_scale), self._p(rec), self._p(stats),
+                                                     self._p(scratch), self._stream()))
+
+    def learn_chain(self, B, words, index, rec, stats, clip, vf_coef, ent_coef, wf, bias, H1, H2, dOut, dH2, dH1, scratch, terms,
+                    running=None):
+        """wf: dict of the bf16 fragment-order weight copies (w1, w2, w3, w3t, w2t: learn_adam), bias: (b1, b2, b3) f32."""
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_learn_chain(self._h, int(B), self._p(words), self._p(index), self._p(rec), self._p(stats),
+                                                   float(clip), float(vf_coef), float(ent_coef), self._p(wf["w1"]), self._p(bias[0]),
+                                                   self._p(wf["w2"]), self._p(bias[1]), self._p(wf["w3"]), self._p(bias[2]),
+                                                   self._p(wf["w3t"]), self._p(wf["w2t"]), self._p(H1), self._p(H2), self._p(dOut),
+                                                   self._p(dH2), self._p(dH1), self._p(scratch), self._p(terms), self._p(running),
+                                                   self._stream()))
+
+    def learn_workspace_bytes(self):
+        return int(self.L.tarok_learn_workspace_bytes(self._h))
+
+    def learn_dw(self, B, words, index, H1, H2, dOut, dH2, dH1, terms, work, grad):
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_learn_dw(self._h, int(B), self._p(words), self._p(index), self._p(H1), self._p(H2), self._p(dOut),
+                                                self._p(dH2), self._p(dH1), self._p(terms), self._p(work), self._p(grad), self._stream()))
+
+    def learn_adam(self, param, grad, m, v, step, wf, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=1.0, gnorm=None, apply=True):
+        wf = wf or {}
+        with torch.cuda.device(self.device):
+            _native.check(self.L.tarok_learn_adam(self._h, self._p(param), self._p(grad), self._p(m), self._p(v), self._p(step), float(lr),
+                                                  float(beta1), float(beta2), float(eps), float(max_norm), self._p(wf.get("w1")),
+                                                  self._p(wf.get("w2")), self._p(wf.get("w3")), self._p(wf.get("w3t")),
+                                                  self._p(wf.get("w2t")), self._p(gnorm), 1 if apply else 0, self._stream()))
+
     def gather_features(self, feature_words, index=None, out=None):
         """tarok_expand_features: [M,4] int64 feature words (+ optional int64 sample index [B]) ->
         [B,256] bf16 network input, gather and bit expansion in one kernel."""

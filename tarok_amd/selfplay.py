@@ -128,6 +128,17 @@ def assign_returns(done, reward, seat):
     return ret, known
 
 
+def allreduce_flat(flat):
+    """Average ONE flat gradient vector over all ranks in place (the fused learner's gradients already are one
+    buffer: no gather, no scatter).  No-op without an initialised process group / with one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    return flat.numel() * flat.element_size()
+
+
 def allreduce_gradients(params):
     """Sum the gradients of `params` over all ranks in ONE flattened all-reduce and
     average them.  No-op without an initialised process group / with one rank."""
@@ -156,11 +167,23 @@ class SelfPlay:
     hidden size the policy runs as tarok_observe -> torch GEMMs -> tarok_sample_policy."""
 
     def __init__(self, env, hidden=256, lr=3e-4, clip=0.2, vf_coef=0.5, ent_coef=0.01, reward_scale=1.0 / 70.0, seed=0,
-                 use_graph=True, fused=None, fused_loss=None, fused_step=None):
+                 use_graph=True, fused=None, fused_loss=None, fused_step=None, fused_learner=None, max_grad_norm=1.0):
         self.env = env
         self.device = env.device
         torch.manual_seed(seed)                       # same initial weights on every rank
         self.net = PolicyNet(hidden).to(self.device)
+        self.lr, self.max_grad_norm = lr, max_grad_norm
+        # ONE flat parameter vector (tarok_env.h TAROK_MLP_*): the module's parameters are views into it, so the
+        # torch paths and the fused learner (tarok_learn_*: flat gradient, flat Adam state) see the same weights
+        self.flat = None
+        if hidden == 256:
+            ps = [self.net.fc1.weight, self.net.fc1.bias, self.net.fc2.weight, self.net.fc2.bias, self.net.head.weight, self.net.head.bias]
+            self.flat = torch.cat([p.detach().reshape(-1) for p in ps]).contiguous()
+            assert self.flat.numel() == K.MLP_PARAMS
+            off = 0
+            for p in ps:
+                p.data = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
         self.opt = torch.optim.Adam(self.net.parameters(), lr=lr)
         self.clip, self.vf_coef, self.ent_coef, self.reward_scale = clip, vf_coef, ent_coef, reward_scale
         self.gen = torch.Generator(device=self.device)
@@ -173,10 +196,36 @@ class SelfPlay:
         self.fused_loss = True if fused_loss is None else bool(fused_loss)
         # policy and env step in one launch per lock-step (tarok_policy_step)
         self.fused_step = self.fused if fused_step is None else bool(fused_step)
+        # the whole update as tarok_learn_* launches: returns, forward + loss + backward chain, weight gradients,
+        # clip + Adam on the flat vectors (update_fused)
+        self.fused_learner = (self.fused and env.device.type == "cuda") if fused_learner is None else bool(fused_learner)
+        assert not self.fused_learner or self.fused, "the fused learner is built for the fused policy (hidden = 256)"
         self._graph, self._buf, self._T = None, None, 0
         self._w = None                                # rollout copies of the weights (bf16) / biases (f32)
+        self._learn = None                            # the fused learner's buffers
+        if self.fused_learner:
+            dev = self.device
+            bf = lambda k: torch.empty(k, dtype=torch.bfloat16, device=dev)
+            self._wf = dict(w1=bf(65536), w2=bf(65536), w3=bf(16384), w3t=bf(16384), w2t=bf(65536))
+            self.gflat = torch.zeros(K.MLP_PARAMS, dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros_like(self.gflat)
+            self.adam_v = torch.zeros_like(self.gflat)
+            self.adam_step = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.sync_weights()
+            f = self.flat
+            sl = lambda a, k: f[a:a + k]
+            # the rollout reads the learner's own copies: fragment-order weights, biases inside the flat vector
+            self._w = [self._wf["w1"].view(256, 256), sl(K.MLP_B1, 256), self._wf["w2"].view(256, 256), sl(K.MLP_B2, 256),
+                       self._wf["w3"].view(64, 256), sl(K.MLP_B3, 64)]
+
+    def sync_weights(self):
+        """Rebuild the kernels' bf16 fragment-order weight copies from the flat parameter vector (after loading a
+        checkpoint or changing the parameters by hand; the fused Adam step keeps them current itself)."""
+        self.env.learn_adam(self.flat, None, None, None, None, self._wf, apply=False)
 
     def _refresh_rollout_weights(self):
+        if self.fused_learner:                        # (tarok_learn_adam wrote them with the update)
+            return
         with torch.no_grad():
             n = self.net
             src = [(n.fc1.weight, torch.bfloat16), (n.fc1.bias, torch.float32), (n.fc2.weight, torch.bfloat16),
@@ -321,18 +370,66 @@ class SelfPlay:
             stats[k] = v / max(1, count)
         return stats
 
+    def _learn_bufs(self, M, B):
+        """Buffers of the fused learner: per-sample records of a rollout of M samples, activations of a minibatch of
+        at most B samples, the weight-gradient workspace."""
+        lb = self._learn
+        if lb is None or lb["M"] != M or lb["B"] < B:
+            dev = self.device
+            f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            act = lambda k: torch.empty((B, k), dtype=torch.bfloat16, device=dev)
+            lb = dict(M=M, B=B, rec=f32(M, 4), stats=f32(4), scratch=f32(max((self.env.n + 255) // 256, (B + 127) // 128), 4),
+                      H1=act(256), H2=act(256), dH2=act(256), dH1=act(256), dOut=act(64), terms=f32(4),
+                      running=torch.zeros(4, dtype=torch.float32, device=dev),
+                      work=torch.empty(self.env.learn_workspace_bytes(), dtype=torch.uint8, device=dev))
+            self._learn = lb
+        return lb
+
+    def update_fused(self, buf, epochs=2, minibatches=8):
+        """The update as fused launches (include/tarok_env.h tarok_learn_*): per rollout one returns kernel; per
+        minibatch the forward + loss + backward chain (activations in LDS, bf16 MFMA), the three weight gradients
+        as one split-K launch, ONE flat gradient all-reduce, and clip + Adam + weight-copy refresh in one launch.
+        No host synchronisation until the statistics are read at the end."""
+        env = self.env
+        T, n = buf["act"].shape
+        M = T * n
+        B = -(-M // minibatches)
+        lb = self._learn_bufs(M, B)
+        env.learn_returns(T, buf["done"], buf["reward"], buf["words"][:T], buf["logp"], buf["val"], buf["act"], self.reward_scale,
+                          lb["rec"], lb["stats"], lb["scratch"])
+        words = buf["obs"].view(M, 4)
+        lb["running"].zero_()
+        nbytes = 0
+        bias = (self._w[1], self._w[3], self._w[5])
+        for _ in range(epochs):
+            perm = torch.randperm(M, device=self.device, generator=self.gen)
+            for idx in perm.chunk(minibatches):
+                b = idx.numel()
+                env.learn_chain(b, words, idx, lb["rec"], lb["stats"], self.clip, self.vf_coef, self.ent_coef, self._wf, bias,
+                                lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["scratch"], lb["terms"], lb["running"])
+                env.learn_dw(b, words, idx, lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["terms"], lb["work"], self.gflat)
+                nbytes = allreduce_flat(self.gflat)
+                env.learn_adam(self.flat, self.gflat, self.adam_m, self.adam_v, self.adam_step, self._wf, lr=self.lr,
+                               max_norm=self.max_grad_norm)
+        run = lb["running"].tolist()
+        cnt = max(1.0, run[3])
+        pi, v, ent = run[0] / cnt, run[1] / cnt, run[2] / cnt
+        return dict(loss=pi + self.vf_coef * v - self.ent_coef * ent, pi_loss=pi, v_loss=v, entropy=ent, allreduce_bytes=nbytes,
+                    known_frac=float(lb["stats"][2]))
+
     def iterate(self, T=48, epochs=2, minibatches=8):
-        """One rollout + one update, timed.  Returns stats incl. env steps/s of the rollout."""
+        """One rollout + one update, timed.  Returns stats incl. env steps/s of the rollout and of the whole
+        iteration (rollout + update)."""
         torch.cuda.synchronize(self.device)
         t0 = time.perf_counter()
         buf = self.collect(T)
         torch.cuda.synchronize(self.device)
         t1 = time.perf_counter()
-        stats = self.update(buf, epochs, minibatches)
+        stats = (self.update_fused if self.fused_learner else self.update)(buf, epochs, minibatches)
         torch.cuda.synchronize(self.device)
         t2 = time.perf_counter()
         stats.update(rollout_s=t1 - t0, update_s=t2 - t1, env_steps=T * self.env.n,
-                     rollout_steps_per_s=T * self.env.n / (t1 - t0),
+                     rollout_steps_per_s=T * self.env.n / (t1 - t0), iteration_steps_per_s=T * self.env.n / (t2 - t0),
                      mean_score=float(buf["reward"].float().sum() / buf["done"].float().sum().clamp(min=1) / 4),
                      env_errors=int((buf["words"] < 0).any()))
         return stats

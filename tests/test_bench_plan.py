@@ -66,7 +66,7 @@ class FakeEnv:
     instances = []
 
     def __init__(self, n, device=0, seed=0, mix=0, game_offset=0):
-        self.n, self.calls = n, []
+        self.n, self.calls, self.seed, self.mix = n, [], seed, mix
         FakeEnv.instances.append(self)
 
     def reset(self, episode=0):
@@ -145,7 +145,19 @@ def test_bench_line_on_a_fake_env(fake_gpu, monkeypatch, capsys, argv):
     p = cfg["launch_plan"]
     runs = [c for c in env.calls if c[0] == "run"]
     assert runs[0][2] == cards and runs[0][3] == p["graph_chunk"] and runs[0][1] >= max(p["graph_chunk"], bench.MIN_WARMUP_LOCK_STEPS)   # warm-up
-    assert runs[1:6] == [("run", p["lock_steps"], cards, p["graph_chunk"])] * 5
+    # five regions over the seeds 0, 1, 2, 0, 1: every seed on its own env, each warmed up untimed like the first
+    region = ("run", p["lock_steps"], cards, p["graph_chunk"])
+    assert env.seed == 0 and runs[1:3] == [region] * 2
+    headline = [e for e in FakeEnv.instances if e.n == 65536 and e.mix == 0]
+    assert [e.seed for e in headline] == [0, 1, 2]
+    for e, regions in zip(headline[1:], (2, 1)):
+        r2 = [c for c in e.calls if c[0] == "run"]
+        assert r2[0] == runs[0] and r2[1:] == [region] * regions
+    assert line["repeats"]["seeds"] == [0, 1, 2, 0, 1] and sorted(line["repeats"]["per_seed"]) == ["0", "1", "2"]
+    assert "%d games ahead" % __import__("tarok_amd").karte.GAMES_AHEAD in bench.describe_mode(bench.plan_region(20, 128))
+    assert line["roofline"]["hbm_frac"] == line["roofline"]["frac"] and ("issue" in line["roofline"]["bound"]) == (cards > 1)
+    assert line["config2"]["headline_mode"]["value"] > 0 and line["config2"]["step_api"]["value"] > 0
+    assert line["roofline_step_api"]["streaming"]["policy_plus_step"]["frac"] > 0
     # the failing self-play leg is visible: error field, side_leg_errors, stderr — and the line is still there
     assert "error" in line["selfplay_ppo"] and line["side_leg_errors"] and "FAILED" in out.err
 
@@ -156,6 +168,20 @@ def test_bench_strict_exits_nonzero_after_printing(fake_gpu, monkeypatch, capsys
         bench.main()
     assert e.value.code == 1
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["side_leg_errors"]
+
+
+def test_the_mode_string_names_the_library_constant():
+    """bench.describe_mode quotes the dealt-ahead depth from tarok_amd.karte, which mirrors include/tarok_env.h,
+    which is what the kernels are compiled with (TK_AHEAD): round 2's line said "seven" with fourteen lines."""
+    import os, re
+    from tarok_amd import karte
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "tarok_env.h")).read()
+    src = open(os.path.join(root, "tarok_amd", "csrc", "tarok_env.hip")).read()
+    assert int(re.search(r"#define TAROK_GAMES_AHEAD (\d+)", hdr).group(1)) == karte.GAMES_AHEAD
+    assert re.search(r"#define TK_AHEAD TAROK_GAMES_AHEAD\b", src)
+    assert int(re.search(r"#define TAROK_MLP_PARAMS (\d+)", hdr).group(1)) == karte.MLP_PARAMS
+    assert "%d games ahead" % karte.GAMES_AHEAD in bench.describe_mode(bench.plan_region(20, 128))
 
 
 def test_profile_provenance_is_flagged_stale(tmp_path, monkeypatch):
