@@ -354,6 +354,7 @@ int tarok_targets_ref(tarok_env *env, int T, const uint64_t *obs_before, const u
 #define TAROK_MLP_W3 131584
 #define TAROK_MLP_B3 147968
 #define TAROK_MLP_PARAMS 148032
+#define TAROK_LEARN_PAD 256 /* padding rows of the activation arrays of tarok_learn_chain / tarok_learn_dw */
 
 /* Returns of a rollout of T lock-steps (rows [T,N] as written by tarok_policy_step): every card is credited with
  * its seat's final score of the game it belongs to, times reward_scale.
@@ -369,8 +370,9 @@ int tarok_learn_returns(tarok_env *env, int T, const uint8_t *done, const int16_
  * rec [M,4]; index NULL: row j): feature gather + expansion -> layers 1-3 -> the loss of tarok_ppo_loss (advantage
  * = (return - value - stats[0]) * stats[1], weight = known) -> dH2, dH1.  Weights: the bf16 fragment-order copies
  * tarok_learn_adam writes (w3t / w2t: of the transposes), biases: pointers into the flat vector.
- *   H1 / H2 / dH2 / dH1 [B,256] bf16, dOut [B,64] bf16 (unscaled: weight w, not w / sum w) for tarok_learn_dw;
- *   scratch [ceil(B/128),4] f32; terms_out [4] f32 = {policy loss, value loss, entropy (weighted means),
+ *   H1 / H2 / dH2 / dH1 [B + TAROK_LEARN_PAD, 256] bf16, dOut [B + TAROK_LEARN_PAD, 64] bf16 (rows B.. are padding that
+ *   tarok_learn_dw may read and ignores; values unscaled: weight w, not w / sum w);
+ *   scratch [ceil(B/96),4] f32; terms_out [4] f32 = {policy loss, value loss, entropy (weighted means),
  *   1 / max(sum w, 1)}; running [4] f32 or NULL: += {the three terms, 1}. */
 int tarok_learn_chain(tarok_env *env, int64_t B, const uint64_t *feature_words, const int64_t *index, const float *rec,
                       const float *stats, float clip, float vf_coef, float ent_coef, const void *w1, const float *b1,

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <utility>
 
 #include "../../include/tarok_env.h"
 
@@ -108,6 +109,7 @@ struct tarok_env {
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
     int n_cus;               // compute units of the device (k_learn_dw's grid), 0 = not asked yet
+    float *adam_sumsq;       // k_learn_gnorm's partial sums
     u64 *stamps;             // diagnostics only
     hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
     // cached graph
@@ -2144,6 +2146,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->adam_sumsq, 1024 * sizeof(float));
     if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 32 * TK_EPOCH_SHARDS * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
@@ -2169,7 +2172,7 @@ void tarok_destroy(tarok_env *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
-    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch); (void)hipFree(e->hist);
+    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch); (void)hipFree(e->hist); (void)hipFree(e->adam_sumsq);
     delete e;
 }
 
@@ -2531,23 +2534,25 @@ int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, co
     a.b1 = b1; a.b2 = b2; a.b3 = b3;
     a.H1 = (uint4 *)H1; a.H2 = (uint4 *)H2; a.dH2 = (uint4 *)dH2; a.dH1 = (uint4 *)dH1; a.dOut = (uint2 *)dOut;
     a.part = (float4 *)scratch;
+    a.stamps = e->stamps;
     unsigned blocks = (unsigned)((B + LN_M - 1) / LN_M);
-    hipLaunchKernelGGL(k_learn_chain, dim3(blocks), dim3(TK_BLOCK), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_learn_chain, dim3(blocks), dim3(LN_CHAIN_THREADS), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_learn_terms, dim3(1), dim3(TK_BLOCK), 0, (hipStream_t)stream, (int)blocks, (const float4 *)scratch,
                        (float4 *)terms_out, (float4 *)running);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
 
-// chunks per layer of k_learn_dw: one workgroup per CU in all, shared out by the bytes a sample costs each layer
-// (layer 2: H1 + dH2 = 1024, layer 1: feature words + dH1 = 544, layer 3: H2 + dOut = 640: the kernel is HBM bound)
+// chunks per layer of k_learn_dw: one workgroup per CU in all.  A tile costs a workgroup about the same in every
+// layer (per-tile overheads, not bytes or MFMAs, set its time at this size), a little more where both operands are
+// 256 wide (layer 2), a little less where the gradient is 64 wide (layer 3): shares 100 : 90 : 66.
 static inline void learn_chunks(tarok_env *e, u32 &c2, u32 &c1, u32 &c3) {
     if (!e->n_cus) {
         hipDeviceProp_t pr;
         e->n_cus = hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
     u32 total = (u32)e->n_cus < 8 ? 8 : (u32)e->n_cus;
-    c2 = total * 1024 / 2208; c1 = total * 544 / 2208; c3 = total - c2 - c1;
+    c2 = total * 100 / 256; c1 = total * 90 / 256; c3 = total - c2 - c1;
 }
 
 int64_t tarok_learn_workspace_bytes(tarok_env *e) {
@@ -2583,7 +2588,10 @@ int tarok_learn_adam(tarok_env *e, float *param, const float *grad, float *m, fl
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
     a.w1 = (__bf16 *)w1; a.w2 = (__bf16 *)w2; a.w3 = (__bf16 *)w3; a.w3t = (__bf16 *)w3t; a.w2t = (__bf16 *)w2t;
     a.gnorm = gnorm_out; a.apply = apply;
-    hipLaunchKernelGGL(k_learn_adam, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    a.sumsq = e->adam_sumsq;
+    if (apply) hipLaunchKernelGGL(k_learn_gnorm, dim3(LN_ADAM_BLOCKS), dim3(LN_ADAM_BLOCK), 0, (hipStream_t)stream, grad, e->adam_sumsq);
+    hipLaunchKernelGGL(k_learn_adam, dim3(LN_ADAM_BLOCKS), dim3(LN_ADAM_BLOCK), 0, (hipStream_t)stream, a);
+    if (apply) hipLaunchKernelGGL(k_learn_step, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }

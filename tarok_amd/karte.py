@@ -47,6 +47,7 @@ OPT_REFILL_FAN = 2        # tarok_set_option
 GAMES_AHEAD = 14          # TAROK_GAMES_AHEAD: games every slot keeps dealt ahead for auto-reset
 # the flat parameter vector of the 256-256-256-64 policy (include/tarok_env.h TAROK_MLP_*)
 MLP_W1, MLP_B1, MLP_W2, MLP_B2, MLP_W3, MLP_B3, MLP_PARAMS = 0, 65536, 65792, 131328, 131584, 147968, 148032
+LEARN_PAD = 256           # TAROK_LEARN_PAD: padding rows of the fused learner's activation arrays
 
 # the reference-layout observation record (include/tarok_env.h TAROK_REF_*)
 REF_ROWS = 56

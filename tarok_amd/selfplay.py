@@ -377,8 +377,8 @@ class SelfPlay:
         if lb is None or lb["M"] != M or lb["B"] < B:
             dev = self.device
             f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            act = lambda k: torch.empty((B, k), dtype=torch.bfloat16, device=dev)
-            lb = dict(M=M, B=B, rec=f32(M, 4), stats=f32(4), scratch=f32(max((self.env.n + 255) // 256, (B + 127) // 128), 4),
+            act = lambda k: torch.zeros((B + K.LEARN_PAD, k), dtype=torch.bfloat16, device=dev)
+            lb = dict(M=M, B=B, rec=f32(M, 4), stats=f32(4), scratch=f32(max((self.env.n + 255) // 256, (B + 95) // 96), 4),
                       H1=act(256), H2=act(256), dH2=act(256), dH1=act(256), dOut=act(64), terms=f32(4),
                       running=torch.zeros(4, dtype=torch.float32, device=dev),
                       work=torch.empty(self.env.learn_workspace_bytes(), dtype=torch.uint8, device=dev))
