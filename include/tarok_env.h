@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TAROK_ABI_VERSION 3
+#define TAROK_ABI_VERSION 4
 #define TAROK_MAX_CARDS_PER_LAUNCH 192 /* tarok_krog_random / tarok_run_random: cards of every game per launch */
 #define TAROK_GAMES_AHEAD 14           /* games every slot keeps dealt ahead for TAROK_AUTO_RESET (tarok_prefetch)  */
 

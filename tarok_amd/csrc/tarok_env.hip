@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -1967,8 +1968,7 @@ __global__ __launch_bounds__(256) void k_targets_ref(int64_t n, int T, const u64
         int found = -1;
         for (int k = 0; k < 4; k++) {
             u64 ob = obs_before[(int64_t)(4 * b + k) * n + i];
-            bool mine = ((u32)(ob >> TAROK_OBS_SEAT_SHIFT) & 3u) == s && action[(int64_t)(4 * b + k) * n + i] < 54 &&
-                        !(ob & TAROK_OBS_DONE & 0) && found < 0;
+            bool mine = ((u32)(ob >> TAROK_OBS_SEAT_SHIFT) & 3u) == s && action[(int64_t)(4 * b + k) * n + i] < 54 && found < 0;
             if (mine) { found = k; legal = ob & TAROK_OBS_MASK; card = action[(int64_t)(4 * b + k) * n + i]; }
         }
         int64_t last = (int64_t)(4 * b + 3) * n + i;
@@ -2545,14 +2545,17 @@ int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, co
 
 // chunks per layer of k_learn_dw: one workgroup per CU in all.  A tile costs a workgroup about the same in every
 // layer (per-tile overheads, not bytes or MFMAs, set its time at this size), a little more where both operands are
-// 256 wide (layer 2), a little less where the gradient is 64 wide (layer 3): shares 100 : 90 : 66.
+// 256 wide (layer 2) or the input is expanded from feature words (layer 1), less where the gradient is 64 wide
+// (layer 3): shares 96 : 108 : 52 (same-box A/B of six settings: profiles/r03_learner_steps.txt).
 static inline void learn_chunks(tarok_env *e, u32 &c2, u32 &c1, u32 &c3) {
     if (!e->n_cus) {
         hipDeviceProp_t pr;
         e->n_cus = hipGetDeviceProperties(&pr, e->device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
     u32 total = (u32)e->n_cus < 8 ? 8 : (u32)e->n_cus;
-    c2 = total * 100 / 256; c1 = total * 90 / 256; c3 = total - c2 - c1;
+    u32 s2 = 96, s1 = 108;
+    if (const char *f = getenv("TAROK_DW_SHARES")) { unsigned a = 0, b = 0; if (sscanf(f, "%u,%u", &a, &b) == 2 && a >= 8 && b >= 8 && a + b <= 248) { s2 = a; s1 = b; } }   // diagnostics (A/B runs)
+    c2 = total * s2 / 256; c1 = total * s1 / 256; c3 = total - c2 - c1;
 }
 
 int64_t tarok_learn_workspace_bytes(tarok_env *e) {

@@ -229,10 +229,11 @@ class TarokVecEnv:
             self.obs_words.copy_(kb["obs"][cards - 1])
         return kb
 
-    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=0, cards_per_launch=None):
+    def run_random(self, n_steps, fused=False, graph_chunk=0, auto_reset=True, prefetch_every=0, cards_per_launch=None, done_rows=True):
         """n_steps lock-steps of the random policy launched from C (optionally graph-replayed).
         cards_per_launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = that many
-        cards per launch (tarok_krog_random); default from `fused`."""
+        cards per launch (tarok_krog_random); default from `fused`.  done_rows=False (one-card modes): done_out = NULL —
+        a consumer reads "finished by this step" off bit 62 of the observation word instead of a byte row."""
         cards = (1 if fused else 0) if cards_per_launch is None else int(cards_per_launch)
         with torch.cuda.device(self.device):
             if cards >= 2:
@@ -243,7 +244,7 @@ class TarokVecEnv:
                 self.obs_words.copy_(kb["obs"][cards - 1])
             else:
                 _native.check(self.L.tarok_run_random(self._h, int(n_steps), cards, int(graph_chunk), int(prefetch_every),
-                                                      self._p(self.action), self._p(self.reward), self._p(self.done),
+                                                      self._p(self.action), self._p(self.reward), self._p(self.done) if done_rows else None,
                                                       self._p(self.obs_words), K.AUTO_RESET if auto_reset else 0,
                                                       self._stream()))
 

@@ -188,6 +188,9 @@ class SelfPlay:
         self.clip, self.vf_coef, self.ent_coef, self.reward_scale = clip, vf_coef, ent_coef, reward_scale
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(1234 + 7919 * sharding.world()[0])
+        self.hgen = torch.Generator()                 # host side: the fused learner's epoch permutations
+        self.hgen.manual_seed(4321 + 7919 * sharding.world()[0])
+        self.shuffle = "affine"
         self.obs_words = env.reset().words.clone()
         self.use_graph = use_graph
         self.fused = (hidden == 256) if fused is None else bool(fused)
@@ -385,6 +388,21 @@ class SelfPlay:
             self._learn = lb
         return lb
 
+    def _epoch_permutation(self, M):
+        """The order in which an epoch visits the rollout's M samples: j -> (a j + b) mod M with a coprime to M and (a, b)
+        drawn per epoch — a permutation whose consecutive entries lie a samples apart, so every minibatch (a run of it)
+        spreads over all lock-steps and slots.  Three elementwise launches instead of torch.randperm's radix sort of M
+        keys (0.18 ms of a 5 ms update at 3.1 M samples).  shuffle = "randperm" selects the latter."""
+        if self.shuffle == "randperm":
+            return torch.randperm(M, device=self.device, generator=self.gen)
+        import math
+        while True:
+            a = int(torch.randint(M // 3, M, (1,), generator=self.hgen)) | 1
+            if math.gcd(a, M) == 1:
+                break
+        b = int(torch.randint(0, M, (1,), generator=self.hgen))
+        return (torch.arange(M, device=self.device, dtype=torch.int64) * a + b) % M
+
     def update_fused(self, buf, epochs=2, minibatches=8):
         """The update as fused launches (include/tarok_env.h tarok_learn_*): per rollout one returns kernel; per
         minibatch the forward + loss + backward chain (activations in LDS, bf16 MFMA), the three weight gradients
@@ -402,7 +420,7 @@ class SelfPlay:
         nbytes = 0
         bias = (self._w[1], self._w[3], self._w[5])
         for _ in range(epochs):
-            perm = torch.randperm(M, device=self.device, generator=self.gen)
+            perm = self._epoch_permutation(M)
             for idx in perm.chunk(minibatches):
                 b = idx.numel()
                 env.learn_chain(b, words, idx, lb["rec"], lb["stats"], self.clip, self.vf_coef, self.ent_coef, self._wf, bias,

@@ -72,7 +72,7 @@ class FakeEnv:
     def reset(self, episode=0):
         self.calls.append(("reset",))
 
-    def run_random(self, n_steps, cards_per_launch=None, graph_chunk=0, auto_reset=True):
+    def run_random(self, n_steps, cards_per_launch=None, graph_chunk=0, auto_reset=True, done_rows=True):
         assert run_random_model(n_steps, cards_per_launch, graph_chunk) != "EINVAL"
         self.calls.append(("run", n_steps, cards_per_launch, graph_chunk))
 

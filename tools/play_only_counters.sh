@@ -15,7 +15,7 @@ for p in ("p1", "p2", "p3", "p4"):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace(" ", "")
-            if "k_play_wide" in k and "<true" in k:
+            if "k_play_wide" in k:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             v = v[len(v) // 2:]
@@ -24,7 +24,7 @@ import sys
 sys.path.insert(0, ".")
 import bench
 res["games"] = $N; res["cards_per_launch"] = 128; res["kernel_src_sha"] = bench.kernel_src_sha()
-res["source"] = "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> -- python3 tools/play_only.py $N; means over the second half of the k_play_wide<true,*> launches (each follows a reset: no refill work)"
+res["source"] = "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> -- python3 tools/play_only.py $N; means over the second half of the k_play_wide launches (each follows a reset: no refill work)"
 json.dump(res, open("$OUT/play_only_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

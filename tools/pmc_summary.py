@@ -44,8 +44,8 @@ def main():
     def traffic(k):
         f, w = kernels[k].get("FETCH_SIZE", {}).get("mean_KB"), kernels[k].get("WRITE_SIZE", {}).get("mean_KB")
         return None if f is None or w is None else int(round((2 * f + w) * 1024))
-    # the multi-card random-policy kernel (k_play / k_play_wide <true, *>): the headline leg dominates its launches
-    play = [k for k in kernels if "k_play" in k and "<true" in k.replace(" ", "")]
+    # the multi-card Bot-policy kernel (k_play_wide<HIST>): the headline leg dominates its launches
+    play = [k for k in kernels if "k_play_wide" in k]
     if play:
         k = max(play, key=lambda q: kernels[q].get("FETCH_SIZE", {}).get("launches", 0))
         res["k_play_kernel"] = k
@@ -53,8 +53,8 @@ def main():
         res["bytes_per_step"] = traffic(k) / (games * cards)
         res["note"] = ("the side legs (one trick / one card per launch) launch the same kernel with fewer cards: the mean over its "
                        "launches is dominated by, but not purely, the %d-card launches; the headline-only passes are in *_headline*" % cards)
-    # the step API's kernel (k_play<false, true>: one card per launch, external action array)
-    step = [k for k in kernels if "k_play" in k and "<false" in k.replace(" ", "")]
+    # the step API's kernel (k_step<false>: one card per launch, external action array)
+    step = [k for k in kernels if "k_step<false" in k.replace(" ", "")]
     if step:
         res["k_step_kernel"] = step[0]
         res["k_step_traffic_bytes_per_launch"] = traffic(step[0])

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round profile pass on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes (separate), N sweep, SQ counters.
+# (Second half — step-API ledger, learner profiles, soak parity — in tools/profile_round_extra.sh: one gpurun call each.)
 # usage: bash tools/profile_round.sh <tag>      (writes gpurun_out/<tag>/; copy the summaries into profiles/)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 CARDS=${2:-128}          # the bench's default cards per launch
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

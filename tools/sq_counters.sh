@@ -16,13 +16,13 @@ for p in ("p1", "p2", "p3"):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace(" ", "")
-            if "k_play" in k and "<true" in k:
+            if "k_play_wide" in k:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             v = v[len(v) // 2:]          # steady state: second half of the launches
             res[k] = {"launches": len(v), "mean": sum(v) / len(v)}
 res["games"] = $N; res["cards_per_launch"] = json.load(open("$OUT/p1.json"))["config"]["cards_per_launch"]; res["kernel_src_sha"] = bench.kernel_src_sha()
-res["source"] = "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> -- python3 bench.py $ARGS; means over the second half of the k_play<true,*> launches"
+res["source"] = "rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> -- python3 bench.py $ARGS; means over the second half of the k_play_wide launches"
 json.dump(res, open("$OUT/sq_counters.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

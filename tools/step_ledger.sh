@@ -17,15 +17,15 @@ run() {   # name lib mode - done reward
   done
   echo "$1 done"
 }
-run two_base "" two d 1 1
-run two_nodone "" two d 0 1
+run two_base "" two d 0 1
+run two_done "" two d 1 1
 run two_noreward "" two d 1 0
-run random_base "" random d 1 1
+run random_base "" random d 0 1
 if [ -f tools/ab/r02.so ]; then
   run two_r02 tools/ab/r02.so two d 1 1
   run random_r02 tools/ab/r02.so random d 1 1
 fi
 unset TAROK_LIB
-python3 tools/step_ledger_summary.py $OUT $N | tee $OUT/step_ledger.txt
+python3 tools/step_ledger_summary.py $OUT $N $OUT/step_ledger.json | tee $OUT/step_ledger.txt
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete

@@ -45,6 +45,20 @@ def main():
                 cells.append("%s %6.1f | %6.1f | %6.1f" % (key, *r[key]))
         tot = sum(r[k][0] for k in r)
         print("%-14s %s   total %.1f B/step = %.2f x 54" % (v, "   ".join(cells), tot, tot / 54.0))
+    if "two_base" in table and len(sys.argv) > 3:               # the JSON bench.py reads for roofline_step_api.streaming
+        import json
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        r = table["two_base"]
+        res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/step_ledger.py "
+                         "%d two d 1 1 96 (tools/step_ledger.sh); FETCH_SIZE doubled" % n,
+               "kernel_src_sha": bench.kernel_src_sha(), "games": n,
+               "step_kernel_bytes_per_step": r["stepR"][0] + r["stepW"][0], "policy_kernel_bytes_per_step": r.get("policyR", (0,))[0] + r.get("policyW", (0,))[0],
+               "two_kernel_bytes_per_step": sum(r[k][0] for k in r),
+               "step_random_bytes_per_step": sum(table["random_base"][k][0] for k in table.get("random_base", {})) or None,
+               "by_card": {k: {"mean": r[k][0], "cards_0_2": r[k][1], "card_3": r[k][2]} for k in r}}
+        with open(sys.argv[3], "w") as fh:
+            json.dump(res, fh, indent=1)
     def d(a, b, key, col=0):
         try:
             return table[a][key][col] - table[b][key][col]
@@ -52,7 +66,7 @@ def main():
             return float("nan")
     print()
     print("array by array (differences between variants, bytes per env step):")
-    print("  done row (1 B):                       W %.2f" % d("two_base", "two_nodone", "stepW"))
+    print("  done row (1 B; two_base leaves it out, like bench.py's step-API legs): W %.2f" % d("two_done", "two_base", "stepW"))
     print("  reward rows of finished games:        W %.2f" % d("two_base", "two_noreward", "stepW"))
     if "two_spec1" in table:            # (round 3's first passes, while the speculative finish-path loads still existed)
         print("  speculative finish-path loads:        R %.2f   (SPEC on - off; 4th-card launches: %.2f)" % (d("two_spec1", "two_spec0", "stepR"), d("two_spec1", "two_spec0", "stepR", 2)))
@@ -60,7 +74,7 @@ def main():
         r = table["two_base"]
         print("  4th card on top of cards 0-2:         R %.2f  W %.2f per 4th-card launch (seat pair 16 W; Counters, next-game line, key, list entry of the games that end)"
               % (r["stepR"][2] - r["stepR"][1], r["stepW"][2] - r["stepW"][1]))
-        print("  cards 0-2 (play pair 16 R + 16 W, seat pair 16 R, card 1 R, observation 8 W, done 1 W = 33 R + 25 W): R %.2f  W %.2f" % (r["stepR"][1], r["stepW"][1]))
+        print("  cards 0-2 (play pair 16 R + 16 W, seat pair 16 R, card 1 R, observation 8 W = 33 R + 24 W): R %.2f  W %.2f" % (r["stepR"][1], r["stepW"][1]))
     if "two_r02" in table:
         print("  round-2 kernel (k_play<false,true>, 64 B/lane of scratch) minus this one:  R %.2f  W %.2f   (cards 0-2: R %.2f  W %.2f)"
               % (d("two_r02", "two_base", "stepR"), d("two_r02", "two_base", "stepW"), d("two_r02", "two_base", "stepR", 1), d("two_r02", "two_base", "stepW", 1)))

@@ -47,7 +47,7 @@ def isa_mix():
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
                            "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     L = open(out).read().split("\n")
-    a = next(i for i, l in enumerate(L) if l.startswith("_Z11k_play_wideILb1ELb0EE"))  # k_play_wide<true, false>: the build the Bot-policy launches use
+    a = next(i for i, l in enumerate(L) if l.startswith("_Z11k_play_wideILb0EE"))  # k_play_wide<false> (no history): the kernel the Bot-policy launches use
     b = next(i for i in range(a, len(L)) if L[i].startswith(".Lfunc_end"))
     K = L[a:b]
     heads = [i for i, l in enumerate(K) if "Loop Header: Depth=1" in l and "Inner" not in l]
