@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): where a workgroup of k_learn_chain spends its cycles (in-kernel s_memtime stamps through
 tarok_debug_stamps): gather + expansion | layer 1 | layer 2 | layer 3 + loss | dH2 | dH1, medians over the workgroups
-of one minibatch of 393,216 samples, and the spread of the workgroups' start and end times."""
+of one minibatch of 393,216 samples (two workgroups share a CU: a workgroup's cycles include the other's turns)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,5 +24,3 @@ for k, nm in enumerate(names):
     print("  %-16s %8d | %8d | %8d" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
 tot = s[:, 6] - s[:, 0]
 print("  %-16s %8d | %8d | %8d" % ("whole workgroup", np.median(tot), np.percentile(tot, 10), np.percentile(tot, 90)))
-print("  launch span (first start to last end): %d cycles; sum of workgroup times / (256 CUs x span) = %.2f workgroups resident per CU"
-      % (s[:, 6].max() - s[:, 0].min(), tot.sum() / 256.0 / (s[:, 6].max() - s[:, 0].min())))
