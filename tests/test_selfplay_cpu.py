@@ -47,6 +47,59 @@ def test_assign_returns_matches_a_plain_loop():
                 assert not known[t, g].item()
 
 
+def test_epoch_permutation_is_a_permutation_that_spreads():
+    """The fused learner's epoch order j -> (a j + b) mod M (SelfPlay._epoch_permutation): a permutation of the M
+    samples for the rollout sizes in use, different from epoch to epoch, and every minibatch (a run of it) reaches
+    all lock-steps of the rollout."""
+    import types
+    for M in (48 * 65536, 48 * 4096, 24 * 4096 + 7, 1000003):
+        me = types.SimpleNamespace(shuffle="affine", hgen=torch.Generator().manual_seed(1), device=torch.device("cpu"), gen=None)
+        p1 = SP.SelfPlay._epoch_permutation(me, M)
+        p2 = SP.SelfPlay._epoch_permutation(me, M)
+        assert p1.dtype == torch.int64 and p1.numel() == M
+        assert torch.equal(torch.sort(p1).values, torch.arange(M)) and torch.equal(torch.sort(p2).values, torch.arange(M))
+        assert not torch.equal(p1, p2)
+        if M % 48 == 0:
+            n = M // 48
+            for idx in p1.chunk(8):
+                assert len(torch.unique(idx // n)) == 48            # every lock-step (row t = sample // n) in every minibatch
+
+
+def _flat_worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from tarok_amd import selfplay, sharding, karte
+    sharding.init_process_group("gloo")
+    g = torch.full((karte.MLP_PARAMS,), float(rank + 1))
+    g[::7] = -2.0 * (rank + 1)
+    nbytes = selfplay.allreduce_flat(g)
+    q.put((rank, g.numpy(), nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_two_ranks_gloo():
+    """The fused learner's collective: ONE all-reduce of the flat gradient vector (TAROK_MLP_PARAMS floats), averaged."""
+    from tarok_amd import karte
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _port()
+    ps = [ctx.Process(target=_flat_worker, args=(r, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, n0), (_, g1, n1) = got
+    assert n0 == n1 == karte.MLP_PARAMS * 4
+    want = np.full(karte.MLP_PARAMS, 1.5, np.float32)
+    want[::7] = -3.0
+    np.testing.assert_allclose(g0, want)
+    np.testing.assert_allclose(g1, want)
+
+
 def _port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
