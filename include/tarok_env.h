@@ -370,6 +370,7 @@ int tarok_learn_returns(tarok_env *env, int T, const uint8_t *done, const int16_
  * rec [M,4]; index NULL: row j): feature gather + expansion -> layers 1-3 -> the loss of tarok_ppo_loss (advantage
  * = (return - value - stats[0]) * stats[1], weight = known) -> dH2, dH1.  Weights: the bf16 fragment-order copies
  * tarok_learn_adam writes (w3t / w2t: of the transposes), biases: pointers into the flat vector.
+ *   Xw [B + TAROK_LEARN_PAD, 4] u64: the samples' feature words in minibatch order (layer 1's input for tarok_learn_dw);
  *   H1 / H2 / dH2 / dH1 [B + TAROK_LEARN_PAD, 256] bf16, dOut [B + TAROK_LEARN_PAD, 64] bf16 (rows B.. are padding that
  *   tarok_learn_dw may read and ignores; values unscaled: weight w, not w / sum w);
  *   scratch [ceil(B/96),4] f32; terms_out [4] f32 = {policy loss, value loss, entropy (weighted means),
@@ -377,13 +378,13 @@ int tarok_learn_returns(tarok_env *env, int T, const uint8_t *done, const int16_
 int tarok_learn_chain(tarok_env *env, int64_t B, const uint64_t *feature_words, const int64_t *index, const float *rec,
                       const float *stats, float clip, float vf_coef, float ent_coef, const void *w1, const float *b1,
                       const void *w2, const float *b2, const void *w3, const float *b3, const void *w3t, const void *w2t,
-                      void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
+                      uint64_t *Xw, void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
                       float *running, void *stream);
 
 /* The weight and bias gradients of that minibatch: grad_out [TAROK_MLP_PARAMS] f32 = terms[3] * (dH^T H per layer,
  * column sums of dH), in the flat parameter order.  workspace: tarok_learn_workspace_bytes(env) bytes. */
 int64_t tarok_learn_workspace_bytes(tarok_env *env);
-int tarok_learn_dw(tarok_env *env, int64_t B, const uint64_t *feature_words, const int64_t *index, const void *H1,
+int tarok_learn_dw(tarok_env *env, int64_t B, const uint64_t *Xw, const void *H1,
                    const void *H2, const void *dOut, const void *dH2, const void *dH1, const float *terms,
                    void *workspace, float *grad_out, void *stream);
 

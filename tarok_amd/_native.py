@@ -139,9 +139,9 @@ def lib():
         L.tarok_targets_ref.restype = i32; L.tarok_targets_ref.argtypes = [vp, i32] + [vp] * 6 + [f32] + [vp] * 3
     if hasattr(L, "tarok_learn_chain"):
         L.tarok_learn_returns.restype = i32; L.tarok_learn_returns.argtypes = [vp, i32] + [vp] * 6 + [f32] + [vp] * 4
-        L.tarok_learn_chain.restype = i32; L.tarok_learn_chain.argtypes = [vp, i64] + [vp] * 4 + [f32] * 3 + [vp] * 17
+        L.tarok_learn_chain.restype = i32; L.tarok_learn_chain.argtypes = [vp, i64] + [vp] * 4 + [f32] * 3 + [vp] * 18
         L.tarok_learn_workspace_bytes.restype = i64; L.tarok_learn_workspace_bytes.argtypes = [vp]
-        L.tarok_learn_dw.restype = i32; L.tarok_learn_dw.argtypes = [vp, i64] + [vp] * 11
+        L.tarok_learn_dw.restype = i32; L.tarok_learn_dw.argtypes = [vp, i64] + [vp] * 10
         L.tarok_learn_adam.restype = i32; L.tarok_learn_adam.argtypes = [vp] * 6 + [f32] * 5 + [vp] * 6 + [i32, vp]
     L.tarok_observe_ref.restype = i32; L.tarok_observe_ref.argtypes = [vp, vp, vp, vp]
     L.tarok_observe_exchange_ref.restype = i32; L.tarok_observe_exchange_ref.argtypes = [vp, vp, vp]

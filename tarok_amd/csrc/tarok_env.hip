@@ -2521,9 +2521,9 @@ int tarok_learn_returns(tarok_env *e, int T, const uint8_t *done, const int16_t 
 int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, const int64_t *index, const float *rec,
                       const float *stats, float clip, float vf_coef, float ent_coef, const void *w1, const float *b1,
                       const void *w2, const float *b2, const void *w3, const float *b3, const void *w3t, const void *w2t,
-                      void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
+                      uint64_t *Xw, void *H1, void *H2, void *dOut, void *dH2, void *dH1, float *scratch, float *terms_out,
                       float *running, void *stream) {
-    if (!e || B < 1 || !feature_words || !rec || !stats || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w3t || !w2t || !H1 || !H2 ||
+    if (!e || B < 1 || !feature_words || !rec || !stats || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w3t || !w2t || !Xw || !H1 || !H2 ||
         !dOut || !dH2 || !dH1 || !scratch || !terms_out)
         return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
@@ -2532,6 +2532,7 @@ int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, co
     a.clip = clip; a.vf_coef = vf_coef; a.ent_coef = ent_coef;
     a.w1 = (const __bf16 *)w1; a.w2 = (const __bf16 *)w2; a.w3 = (const __bf16 *)w3; a.w3t = (const __bf16 *)w3t; a.w2t = (const __bf16 *)w2t;
     a.b1 = b1; a.b2 = b2; a.b3 = b3;
+    a.Xw = (ulonglong2 *)Xw;
     a.H1 = (uint4 *)H1; a.H2 = (uint4 *)H2; a.dH2 = (uint4 *)dH2; a.dH1 = (uint4 *)dH1; a.dOut = (uint2 *)dOut;
     a.part = (float4 *)scratch;
     a.stamps = e->stamps;
@@ -2565,15 +2566,15 @@ int64_t tarok_learn_workspace_bytes(tarok_env *e) {
     return (int64_t)sizeof(float) * ((int64_t)(c2 + c1) * 65792 + (int64_t)c3 * 16448);
 }
 
-int tarok_learn_dw(tarok_env *e, int64_t B, const uint64_t *feature_words, const int64_t *index, const void *H1, const void *H2,
+int tarok_learn_dw(tarok_env *e, int64_t B, const uint64_t *Xw, const void *H1, const void *H2,
                    const void *dOut, const void *dH2, const void *dH1, const float *terms, void *workspace, float *grad_out,
                    void *stream) {
-    if (!e || B < 1 || !feature_words || !H1 || !H2 || !dOut || !dH2 || !dH1 || !terms || !workspace || !grad_out) return TAROK_EINVAL;
+    if (!e || B < 1 || !Xw || !H1 || !H2 || !dOut || !dH2 || !dH1 || !terms || !workspace || !grad_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     u32 c2, c1, c3;
     learn_chunks(e, c2, c1, c3);
-    hipLaunchKernelGGL(k_learn_dw, dim3(c2 + c1 + c3), dim3(TK_BLOCK), 0, (hipStream_t)stream, B, c2, c1, c3, (const u64 *)feature_words,
-                       index, (const uint4 *)H1, (const uint4 *)H2, (const uint4 *)dOut, (const uint4 *)dH2, (const uint4 *)dH1,
+    hipLaunchKernelGGL(k_learn_dw, dim3(c2 + c1 + c3), dim3(TK_BLOCK), 0, (hipStream_t)stream, B, c2, c1, c3, (const u64 *)Xw,
+                       (const uint4 *)H1, (const uint4 *)H2, (const uint4 *)dOut, (const uint4 *)dH2, (const uint4 *)dH1,
                        (float *)workspace);
     hipLaunchKernelGGL(k_learn_reduce, dim3((LN_P + TK_BLOCK - 1) / TK_BLOCK), dim3(TK_BLOCK), 0, (hipStream_t)stream, c2, c1, c3,
                        (const float *)workspace, (const float4 *)terms, grad_out);
@@ -2592,9 +2593,8 @@ int tarok_learn_adam(tarok_env *e, float *param, const float *grad, float *m, fl
     a.w1 = (__bf16 *)w1; a.w2 = (__bf16 *)w2; a.w3 = (__bf16 *)w3; a.w3t = (__bf16 *)w3t; a.w2t = (__bf16 *)w2t;
     a.gnorm = gnorm_out; a.apply = apply;
     a.sumsq = e->adam_sumsq;
-    if (apply) hipLaunchKernelGGL(k_learn_gnorm, dim3(LN_ADAM_BLOCKS), dim3(LN_ADAM_BLOCK), 0, (hipStream_t)stream, grad, e->adam_sumsq);
+    if (apply) hipLaunchKernelGGL(k_learn_gnorm, dim3(LN_ADAM_BLOCKS), dim3(LN_ADAM_BLOCK), 0, (hipStream_t)stream, grad, e->adam_sumsq, step);
     hipLaunchKernelGGL(k_learn_adam, dim3(LN_ADAM_BLOCKS), dim3(LN_ADAM_BLOCK), 0, (hipStream_t)stream, a);
-    if (apply) hipLaunchKernelGGL(k_learn_step, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -2603,9 +2603,9 @@ int tarok_learn_returns(tarok_env *, int, const uint8_t *, const int16_t *, cons
                         float, float *, float *, float *, void *) { return TAROK_EINVAL; }
 int tarok_learn_chain(tarok_env *, int64_t, const uint64_t *, const int64_t *, const float *, const float *, float, float, float,
                       const void *, const float *, const void *, const float *, const void *, const float *, const void *, const void *,
-                      void *, void *, void *, void *, void *, float *, float *, float *, void *) { return TAROK_EINVAL; }
+                      uint64_t *, void *, void *, void *, void *, void *, float *, float *, float *, void *) { return TAROK_EINVAL; }
 int64_t tarok_learn_workspace_bytes(tarok_env *) { return 0; }
-int tarok_learn_dw(tarok_env *, int64_t, const uint64_t *, const int64_t *, const void *, const void *, const void *, const void *,
+int tarok_learn_dw(tarok_env *, int64_t, const uint64_t *, const void *, const void *, const void *, const void *,
                    const void *, const float *, void *, float *, void *) { return TAROK_EINVAL; }
 int tarok_learn_adam(tarok_env *, float *, const float *, float *, float *, int32_t *, float, float, float, float, float, void *, void *,
                      void *, void *, void *, float *, int, void *) { return TAROK_EINVAL; }

@@ -411,23 +411,23 @@ class TarokVecEnv:
                                                      self._p(val), self._p(act), float(reward_scale), self._p(rec), self._p(stats),
                                                      self._p(scratch), self._stream()))
 
-    def learn_chain(self, B, words, index, rec, stats, clip, vf_coef, ent_coef, wf, bias, H1, H2, dOut, dH2, dH1, scratch, terms,
+    def learn_chain(self, B, words, index, rec, stats, clip, vf_coef, ent_coef, wf, bias, Xw, H1, H2, dOut, dH2, dH1, scratch, terms,
                     running=None):
         """wf: dict of the bf16 fragment-order weight copies (w1, w2, w3, w3t, w2t: learn_adam), bias: (b1, b2, b3) f32."""
         with torch.cuda.device(self.device):
             _native.check(self.L.tarok_learn_chain(self._h, int(B), self._p(words), self._p(index), self._p(rec), self._p(stats),
                                                    float(clip), float(vf_coef), float(ent_coef), self._p(wf["w1"]), self._p(bias[0]),
                                                    self._p(wf["w2"]), self._p(bias[1]), self._p(wf["w3"]), self._p(bias[2]),
-                                                   self._p(wf["w3t"]), self._p(wf["w2t"]), self._p(H1), self._p(H2), self._p(dOut),
+                                                   self._p(wf["w3t"]), self._p(wf["w2t"]), self._p(Xw), self._p(H1), self._p(H2), self._p(dOut),
                                                    self._p(dH2), self._p(dH1), self._p(scratch), self._p(terms), self._p(running),
                                                    self._stream()))
 
     def learn_workspace_bytes(self):
         return int(self.L.tarok_learn_workspace_bytes(self._h))
 
-    def learn_dw(self, B, words, index, H1, H2, dOut, dH2, dH1, terms, work, grad):
+    def learn_dw(self, B, Xw, H1, H2, dOut, dH2, dH1, terms, work, grad):
         with torch.cuda.device(self.device):
-            _native.check(self.L.tarok_learn_dw(self._h, int(B), self._p(words), self._p(index), self._p(H1), self._p(H2), self._p(dOut),
+            _native.check(self.L.tarok_learn_dw(self._h, int(B), self._p(Xw), self._p(H1), self._p(H2), self._p(dOut),
                                                 self._p(dH2), self._p(dH1), self._p(terms), self._p(work), self._p(grad), self._stream()))
 
     def learn_adam(self, param, grad, m, v, step, wf, lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=1.0, gnorm=None, apply=True):

@@ -383,6 +383,7 @@ class SelfPlay:
             act = lambda k: torch.zeros((B + K.LEARN_PAD, k), dtype=torch.bfloat16, device=dev)
             lb = dict(M=M, B=B, rec=f32(M, 4), stats=f32(4), scratch=f32(max((self.env.n + 255) // 256, (B + 95) // 96), 4),
                       H1=act(256), H2=act(256), dH2=act(256), dH1=act(256), dOut=act(64), terms=f32(4),
+                      Xw=torch.zeros((B + K.LEARN_PAD, 4), dtype=torch.int64, device=dev),
                       running=torch.zeros(4, dtype=torch.float32, device=dev),
                       work=torch.empty(self.env.learn_workspace_bytes(), dtype=torch.uint8, device=dev))
             self._learn = lb
@@ -424,8 +425,8 @@ class SelfPlay:
             for idx in perm.chunk(minibatches):
                 b = idx.numel()
                 env.learn_chain(b, words, idx, lb["rec"], lb["stats"], self.clip, self.vf_coef, self.ent_coef, self._wf, bias,
-                                lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["scratch"], lb["terms"], lb["running"])
-                env.learn_dw(b, words, idx, lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["terms"], lb["work"], self.gflat)
+                                lb["Xw"], lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["scratch"], lb["terms"], lb["running"])
+                env.learn_dw(b, lb["Xw"], lb["H1"], lb["H2"], lb["dOut"], lb["dH2"], lb["dH1"], lb["terms"], lb["work"], self.gflat)
                 nbytes = allreduce_flat(self.gflat)
                 env.learn_adam(self.flat, self.gflat, self.adam_m, self.adam_v, self.adam_step, self._wf, lr=self.lr,
                                max_norm=self.max_grad_norm)

@@ -183,7 +183,9 @@ def test_learn_chain_and_dw_vs_torch_autograd(T, B):
     H1, H2, dH2, dH1, dOut = act_t(256), act_t(256), act_t(256), act_t(256), act_t(64)
     scratch = torch.empty(((B + 95) // 96, 4), device="cuda")
     terms = torch.empty(4, device="cuda"); running = torch.zeros(4, device="cuda")
-    env.learn_chain(B, words, idx, rec, stats, clip, vf, ent_c, wf, bias, H1, H2, dOut, dH2, dH1, scratch, terms, running)
+    Xw = torch.zeros((B + K.LEARN_PAD, 4), dtype=torch.int64, device="cuda")
+    env.learn_chain(B, words, idx, rec, stats, clip, vf, ent_c, wf, bias, Xw, H1, H2, dOut, dH2, dH1, scratch, terms, running)
+    assert torch.equal(Xw[:B], words[idx])                       # the feature words in minibatch order
     # activations: equal to the reference up to a bf16 ulp where the f32 sums round differently
     for got, want, name in ((H1, h1, "H1"), (H2, h2, "H2")):
         d = (got[:B].float() - want.detach()).abs()
@@ -199,12 +201,13 @@ def test_learn_chain_and_dw_vs_torch_autograd(T, B):
         scale = want.abs().max().item()
         assert err.max().item() < tol * scale + 1e-9, (name, err.max().item(), scale)
     assert (dOut[:B, 55:] == 0).all().item() and (dOut[:B, :54][~legal] == 0).all().item()
+    Xw[B:] = -1
     for t_ in (H1, H2, dH2, dH1, dOut):
         t_[B:].uniform_(-3, 3)                                # (the padding rows may hold anything: tarok_learn_dw ignores them)
     # weight and bias gradients
     work = torch.empty(env.learn_workspace_bytes(), dtype=torch.uint8, device="cuda")
     grad = torch.zeros(K.MLP_PARAMS, device="cuda")
-    env.learn_dw(B, words, idx, H1, H2, dOut, dH2, dH1, terms, work, grad)
+    env.learn_dw(B, Xw, H1, H2, dOut, dH2, dH1, terms, work, grad)
     off = 0
     for q, name in zip(Wq, ("W1", "b1", "W2", "b2", "W3", "b3")):
         gk = grad[off:off + q.numel()].view_as(q)
