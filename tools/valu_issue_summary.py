@@ -101,13 +101,12 @@ def main():
     tot = sum(priced.values()) + sum(unpriced.values())
     cyc = sum(n * table[k]["simd_cost"] for k, n in priced.items()) + sum(unpriced.values()) * half_cost
     lone = sorted(t["lone_wave"] for t in table.values())[len(table) // 2]
-    h = hashlib.sha256()
-    for p in ("tarok_amd/csrc/tarok_env.hip", "tarok_amd/csrc/tarok_device.h", "tarok_amd/csrc/deal_network.inc", "include/tarok_env.h"):
-        h.update(open(os.path.join(ROOT, p), "rb").read())
+    sys.path.insert(0, ROOT)
+    import bench                                          # (the same hash bench.py compares with: all of _native.DEPS)
     res = {
-        "source": "tools/valu_issue (gfx950, %d iterations x %d instructions per wave; raw: %s) + static mix of k_play<true>'s "
+        "source": "tools/valu_issue (gfx950, %d iterations x %d instructions per wave; raw: %s) + static mix of k_play_wide's "
                   "trick-aligned card loop (hipcc -S)" % (raw["iters"], raw["instructions_per_iteration"], os.path.basename(raw_path)),
-        "kernel_src_sha": h.hexdigest()[:16],
+        "kernel_src_sha": bench.kernel_src_sha(),
         "clock_hz": raw["clock_mhz_mean"] * 1e6,
         "lone_wave_cycles_per_instruction": lone,
         "findings": [
