@@ -411,6 +411,10 @@ def main():
             if pma and "k_step_traffic_bytes_per_launch" in pma:
                 tr = pma["k_step_traffic_bytes_per_launch"] + pma.get("k_policy_traffic_bytes_per_launch", 0)
                 out["roofline_step_api"].update(traffic=tr, traffic_over_algorithmic=tr / float(ALGO_BYTES_PER_STEP * n),
+                                                step_kernel_traffic=pma["k_step_traffic_bytes_per_launch"],
+                                                step_kernel_traffic_over_algorithmic=pma["k_step_traffic_bytes_per_launch"] / float(ALGO_BYTES_PER_STEP * n),
+                                                traffic_note="traffic = k_step<false> + k_policy (the stand-in policy reads the observation word "
+                                                             "and the game's RNG key: 17 B/step that are the policy's, not the env's)",
                                                 traffic_provenance=pma_prov)
         # (a0) the same path where it streams: 4 M games (the state no longer fits the caches; 54 B/step against 8 TB/s
         # is a meaningful fraction here).  Its own env; skipped when the batch is not the default (N sweeps).
@@ -431,6 +435,8 @@ def main():
                 if led:
                     stream["traffic_bytes_per_step"] = led.get("two_kernel_bytes_per_step")
                     stream["traffic_over_algorithmic"] = led.get("two_kernel_bytes_per_step", 0) / float(ALGO_BYTES_PER_STEP)
+                    stream["step_kernel_traffic_over_algorithmic"] = led.get("step_kernel_bytes_per_step", 0) / float(ALGO_BYTES_PER_STEP)
+                    stream["step_random_traffic_over_algorithmic"] = (led.get("step_random_bytes_per_step") or 0) / float(ALGO_BYTES_PER_STEP)
                     stream["traffic_provenance"] = led_prov
                 if rank == 0:
                     out["roofline_step_api"]["streaming"] = stream
