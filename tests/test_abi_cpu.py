@@ -63,6 +63,19 @@ def test_create_rejects_bad_arguments(libpath):
     assert L.tarok_num_games(None) == 0
 
 
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu(libpath):
+    """The entry points added in round 3 validate their arguments before any HIP call (no compute without a GPU)."""
+    from tarok_amd import _native
+    L = _native.lib()
+    assert L.tarok_set_option(None, 2, 4) == -1
+    assert L.tarok_learn_workspace_bytes(None) == 0
+    z = ctypes.c_void_p(0)
+    assert L.tarok_targets_ref(None, 48, z, z, z, z, z, z, 0.1, z, z, z) == -1
+    assert L.tarok_learn_returns(None, 48, z, z, z, z, z, z, 1.0, z, z, z, z) == -1
+    assert L.tarok_learn_dw(None, 128, z, z, z, z, z, z, z, z, z, z) == -1
+    assert L.tarok_learn_adam(None, z, z, z, z, z, 1e-3, 0.9, 0.999, 1e-8, 1.0, z, z, z, z, z, z, 1, z) == -1
+
+
 def test_product_never_touches_the_oracle():
     """tarok_amd/ and bench.py's GPU legs must not import or link oracle/."""
     pkg = os.path.join(ROOT, "tarok_amd")
