@@ -2,12 +2,18 @@
 """Summarise tools/step_ledger.sh's PMC passes: bytes per env step of the step kernel and of k_policy, per variant,
 split into the launches that play cards 0-2 of a trick and the ones that play the 4th card (every slot is
 trick-aligned: dispatch j of the step kernel plays card j mod 4), then the ledger array by array as differences.
-FETCH_SIZE is doubled (gfx950 counts a coalesced read stream at half: MI355X_MICROARCH.md, HBM section)."""
+FETCH_SIZE is doubled (gfx950 counts a coalesced read stream at half: MI355X_MICROARCH.md, HBM section).
+tools/fetch_calib (profiles/r03_fetch_calibration.txt) calibrated the counters on the step kernels' own access shapes:
+streamed reads of 16 / 8 / 1 B per lane read 0.50 of their bytes (so x 2 is right for them), but the SPARSE record reads
+of the lanes whose game ends (64-byte next-game lines, 32-byte Counters) read 1.00 / 1.79 of theirs — the counter already
+holds the bytes fetched, doubling it counts them twice.  The "calibrated" figures take the reads that a 4th-card launch
+has on top of a cards-0-2 launch (the sparse ones) once instead of twice."""
 import csv, glob, os, sys, collections
 
 def collect(d, counter):
     per = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                                       # (one pass per directory: the newest, if an older one was merged in)
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == counter:
@@ -35,6 +41,11 @@ def main():
                 b = lambda xs: mul * 1024.0 * sum(xs) / len(xs) / n if xs else float("nan")
                 row[short + cname] = (b(vals), b(c012), b(c3))
         table[v] = row
+    def calibrated(r):
+        """bytes per step with the 4th card's extra (sparse) reads counted once: (total, step kernel alone)"""
+        extra = (r["stepR"][2] - r["stepR"][1]) / 2.0           # what the doubling added on a 4th-card launch
+        tot = sum(r[k][0] for k in r) - extra / 4.0
+        return tot, r["stepR"][0] + r["stepW"][0] - extra / 4.0
     print("step-API traffic ledger, %d games, MIX_ALL, auto-reset; bytes per env step (mean | cards 0-2 | 4th card)" % n)
     print("R = FETCH_SIZE x 2, W = WRITE_SIZE; step = the step kernel (k_step<..>, r02: k_play<false,true> / k_play_wide<true,false>)")
     for v in variants:
@@ -44,7 +55,8 @@ def main():
             if key in r:
                 cells.append("%s %6.1f | %6.1f | %6.1f" % (key, *r[key]))
         tot = sum(r[k][0] for k in r)
-        print("%-14s %s   total %.1f B/step = %.2f x 54" % (v, "   ".join(cells), tot, tot / 54.0))
+        cal = calibrated(r)[0] if "stepR" in r else tot
+        print("%-14s %s   total %.1f B/step = %.2f x 54   calibrated %.1f = %.2f x" % (v, "   ".join(cells), tot, tot / 54.0, cal, cal / 54.0))
     if "two_base" in table and len(sys.argv) > 3:               # the JSON bench.py reads for roofline_step_api.streaming
         import json
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -55,6 +67,9 @@ def main():
                "kernel_src_sha": bench.kernel_src_sha(), "games": n,
                "step_kernel_bytes_per_step": r["stepR"][0] + r["stepW"][0], "policy_kernel_bytes_per_step": r.get("policyR", (0,))[0] + r.get("policyW", (0,))[0],
                "two_kernel_bytes_per_step": sum(r[k][0] for k in r),
+               "two_kernel_bytes_per_step_calibrated": calibrated(r)[0], "step_kernel_bytes_per_step_calibrated": calibrated(r)[1],
+               "step_random_bytes_per_step_calibrated": calibrated(table["random_base"])[0] if "random_base" in table else None,
+               "calibration": "FETCH_SIZE x 2 for the streamed reads, x 1 for the sparse record reads of ending games (profiles/r03_fetch_calibration.txt)",
                "step_random_bytes_per_step": sum(table["random_base"][k][0] for k in table.get("random_base", {})) or None,
                "by_card": {k: {"mean": r[k][0], "cards_0_2": r[k][1], "card_3": r[k][2]} for k in r}}
         with open(sys.argv[3], "w") as fh:
