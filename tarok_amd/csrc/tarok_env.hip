@@ -295,6 +295,36 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
     action[i] = (uint8_t)a;
 }
 
+// The same for four games per thread, the form the host picks when the arrays allow 16-byte loads: a lane of the
+// one-game kernel has 16 bytes in flight, the chip 8 MB, and at 4 M games the launch ran at the memory LATENCY
+// (16.3 us for 71 MB, profiles/r03_step_durations.txt).  A workgroup takes 1,024 consecutive games; thread t the
+// pairs (2t, 2t+1) of its first and of its second half, so that every load is a contiguous 16 bytes per lane and
+// every store two bytes per lane of one 128-byte line per wave.
+__global__ __launch_bounds__(TK_BLOCK) void k_policy_x4(int64_t n, const u64 *__restrict__ obs,
+                                                       const u64 *__restrict__ gkey, uint8_t *__restrict__ action) {
+    int64_t base = (int64_t)blockIdx.x * (4 * TK_BLOCK);
+    if (base + 4 * TK_BLOCK <= n) {
+        int64_t p0 = base + 2 * threadIdx.x, p1 = p0 + 2 * TK_BLOCK;
+        ulonglong2 o0 = *reinterpret_cast<const ulonglong2 *>(obs + p0), o1 = *reinterpret_cast<const ulonglong2 *>(obs + p1);
+        ulonglong2 k0 = *reinterpret_cast<const ulonglong2 *>(gkey + p0), k1 = *reinterpret_cast<const ulonglong2 *>(gkey + p1);
+        auto one = [](u64 o, u64 key) __attribute__((always_inline)) {
+            u64 m = o & TAROK_OBS_MASK;
+            return m ? policy_action(key, (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m) : 255u;
+        };
+        u32 a0 = one(o0.x, k0.x) | (one(o0.y, k0.y) << 8), a1 = one(o1.x, k1.x) | (one(o1.y, k1.y) << 8);
+        *reinterpret_cast<uint16_t *>(action + p0) = (uint16_t)a0;
+        *reinterpret_cast<uint16_t *>(action + p1) = (uint16_t)a1;
+        return;
+    }
+    for (int64_t i = base + threadIdx.x; i < n; i += TK_BLOCK) {       // the last, partial workgroup
+        u64 o = obs[i];
+        u64 m = o & TAROK_OBS_MASK;
+        u32 a = 255;
+        if (m) a = policy_action(gkey[i], (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m);
+        action[i] = (uint8_t)a;
+    }
+}
+
 // Launch parity (see the file header) without a host counter.  The workgroups of step launches are counted
 // as they START, modulo twice their number G per launch (every step launch of an env has the same grid):
 // launch L begins with the count at (L mod 2) * G; every workgroup reads the count together with its first
@@ -2267,11 +2297,19 @@ int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t
     return TAROK_OK;
 }
 
+// k_policy_x4 wherever the caller's arrays allow its 16-byte loads and 2-byte stores (torch allocations do)
+static inline void launch_policy(tarok_env *e, const uint64_t *obs, uint8_t *action, hipStream_t s) {
+    if ((((uintptr_t)obs & 15) | ((uintptr_t)action & 1)) == 0)
+        hipLaunchKernelGGL(k_policy_x4, dim3((unsigned)((e->n + 4 * TK_BLOCK - 1) / (4 * TK_BLOCK))), dim3(TK_BLOCK), 0, s, e->n,
+                           (const u64 *)obs, e->gkey, action);
+    else
+        hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, (const u64 *)obs, e->gkey, action);
+}
+
 int tarok_policy_random(tarok_env *e, const uint64_t *obs, uint8_t *action_out, void *stream) {
     if (!e || !obs || !action_out) return TAROK_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, (const u64 *)obs,
-                       e->gkey, action_out);
+    launch_policy(e, obs, action_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 }
@@ -2301,7 +2339,7 @@ static inline void launch_one(tarok_env *e, int cards, uint8_t *action, int16_t 
     if (cards >= 1) {
         launch_play(e, true, cards, e->n, nullptr, cards >= 2 ? action : nullptr, reward, done, nullptr, obs, flags, s);
     } else {
-        hipLaunchKernelGGL(k_policy, grid_for(e->n), dim3(TK_BLOCK), 0, s, e->n, (const u64 *)obs, e->gkey, action);
+        launch_policy(e, obs, action, s);
         launch_play(e, false, 1, e->n, action, nullptr, reward, done, nullptr, obs, flags, s);
     }
 }

@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(fh):
             per[r["Kernel_Name"].split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 for name, v in sorted(per.items()):
-    if not ("k_step" in name or "k_play" in name or name.endswith("k_policy")):
+    if not ("k_step" in name or "k_play" in name or "k_policy" in name):
         continue
     v = [x for _, x in sorted(v)][2 * period:]
     by = [[x for j, x in enumerate(v) if j % period == c] for c in range(period)]
