@@ -399,7 +399,7 @@ def main():
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
         if rank == 0:
             ach = ALGO_BYTES_PER_STEP * n / (us0 * 1e-6) / 1e9
-            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step) behind k_policy (tarok_policy_random)",
+            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step) behind k_policy_x4 (tarok_policy_random)",
                                         "accounting": "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step" % n,
                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                         "us_per_lock_step": us0, "traffic": None,

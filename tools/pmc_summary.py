@@ -63,7 +63,7 @@ def main():
     if step:
         res["k_step_kernel"] = step[0]
         res["k_step_traffic_bytes_per_launch"] = traffic(step[0])
-        pol = [k for k in kernels if k.endswith("k_policy")]
+        pol = [k for k in kernels if k.endswith(("k_policy", "k_policy_x4"))]
         if pol:
             res["k_policy_traffic_bytes_per_launch"] = traffic(pol[0])
     with open(out, "w") as fh:

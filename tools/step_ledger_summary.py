@@ -28,9 +28,10 @@ def main():
         fe, wr = collect(os.path.join(out, v + "_FETCH_SIZE"), "FETCH_SIZE"), collect(os.path.join(out, v + "_WRITE_SIZE"), "WRITE_SIZE")
         row = {}
         for name in sorted(set(fe) | set(wr)):
-            if not ("k_step" in name or "k_play" in name or name.endswith("k_policy")):
+            is_policy = name.strip() in ("k_policy", "k_policy_x4")          # (tarok_policy_random's two forms; not k_policy_step / _mlp)
+            if not ("k_step" in name or "k_play" in name or is_policy):
                 continue
-            short = "policy" if name.endswith("k_policy") else "step"
+            short = "policy" if is_policy else "step"
             for cname, per, mul in (("R", fe, 2.0), ("W", wr, 1.0)):
                 vals = per.get(name, [])[8:]                    # (skip the first two tricks after the reset)
                 if not vals:
