@@ -295,9 +295,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
     action[i] = (uint8_t)a;
 }
 
-// The same for four games per thread, the form the host picks when the arrays allow 16-byte loads: a lane of the
+// The same for four games per thread, the form the host picks for batches that stream (launch_policy): a lane of the
 // one-game kernel has 16 bytes in flight, the chip 8 MB, and at 4 M games the launch ran at the memory LATENCY
-// (16.3 us for 71 MB, profiles/r03_step_durations.txt).  A workgroup takes 1,024 consecutive games; thread t the
+// (16.3 us for 71 MB, profiles/r03_step_durations.txt; this form 13.0 us).  A workgroup takes 1,024 consecutive games; thread t the
 // pairs (2t, 2t+1) of its first and of its second half, so that every load is a contiguous 16 bytes per lane and
 // every store two bytes per lane of one 128-byte line per wave.
 __global__ __launch_bounds__(TK_BLOCK) void k_policy_x4(int64_t n, const u64 *__restrict__ obs,
@@ -2297,9 +2297,11 @@ int tarok_step(tarok_env *e, const uint8_t *action, int16_t *reward_out, uint8_t
     return TAROK_OK;
 }
 
-// k_policy_x4 wherever the caller's arrays allow its 16-byte loads and 2-byte stores (torch allocations do)
+// k_policy_x4 where the batch streams (from 2^21 games; at 65,536 games its four cards in a row are 0.4 us of latency more
+// per launch than the one-game kernel, at 2^20 the two are equal: profiles/r03_ab_step.txt) and the caller's arrays
+// allow its 16-byte loads and 2-byte stores (torch allocations do)
 static inline void launch_policy(tarok_env *e, const uint64_t *obs, uint8_t *action, hipStream_t s) {
-    if ((((uintptr_t)obs & 15) | ((uintptr_t)action & 1)) == 0)
+    if (e->n >= (1 << 21) && (((uintptr_t)obs & 15) | ((uintptr_t)action & 1)) == 0)
         hipLaunchKernelGGL(k_policy_x4, dim3((unsigned)((e->n + 4 * TK_BLOCK - 1) / (4 * TK_BLOCK))), dim3(TK_BLOCK), 0, s, e->n,
                            (const u64 *)obs, e->gkey, action);
     else

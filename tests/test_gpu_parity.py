@@ -186,31 +186,34 @@ def test_ragged_sizes(T, O, S, n):
 
 
 def test_policy_kernel_forms_agree_with_the_oracle(T, O, S):
-    """tarok_policy_random's two kernels — four games per thread when the caller's arrays allow 16-byte loads, one game
-    per thread otherwise (an observation array 8 bytes off a 16-byte boundary, an odd action address) — and the partial
-    last workgroup of the first: every card equals the oracle's policy_action on the slot's key, step and legal mask."""
+    """tarok_policy_random's two kernels — four games per thread from 2^21 games on when the caller's arrays allow
+    16-byte loads, one game per thread otherwise (an observation array 8 bytes off a 16-byte boundary, an odd action
+    address) — and the partial last workgroup of the first: the cards of the two agree on every slot, and equal the
+    oracle's policy_action on the slot's key, step and legal mask (the last three workgroups and one slot in 61)."""
     import torch
     from tarok_amd import _native
-    n = 5 * 1024 - 120                               # four whole workgroups of k_policy_x4 and a partial one
+    n = (1 << 21) + 5 * 1024 - 120                   # whole workgroups of k_policy_x4 (1,024 games each) and a partial one
     env = T.TarokVecEnv(n, seed=5, mix=S.MIX_ALL)
     obs = env.reset(episode=0)
     for t in range(7):
         obs, _, _ = env.step(env.policy_random(obs))
     words = obs.words.clone()
     w = words.cpu().numpy().view(np.uint64)
+    idx = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(n - 3 * 1024, n), np.arange(0, 2048)]))
     want = np.array([O.policy_action(O.game_key(5, i, 0), (int(w[i]) >> T.karte.OBS_STEP_SHIFT) & 63, int(w[i]) & T.karte.OBS_MASK)
-                     if int(w[i]) & T.karte.OBS_MASK else 255 for i in range(n)], np.uint8)      # (a Berac that is over: no card)
-    assert (want == 255).any() and (want != 255).sum() > n // 2
-    got = env.policy_random(T.Obs(words)).cpu().numpy().copy()
-    assert (got == want).all()
+                     if int(w[i]) & T.karte.OBS_MASK else 255 for i in idx], np.uint8)           # (a Berac that is over: no card)
+    assert (want == 255).any() and (want != 255).sum() > len(idx) // 2
+    assert words.data_ptr() % 16 == 0 and env.action.data_ptr() % 2 == 0
+    got = env.policy_random(T.Obs(words)).cpu().numpy().copy()          # k_policy_x4
+    assert (got[idx] == want).all()
     shifted = torch.zeros(n + 1, dtype=words.dtype, device=words.device)
     shifted[1:] = words
     abuf = torch.zeros(n + 1, dtype=torch.uint8, device=words.device)
-    for wv, av in ((shifted[1:], abuf[:n]), (words, abuf[1:]), (shifted[1:], abuf[1:])):
+    for wv, av in ((shifted[1:], abuf[:n]), (words, abuf[1:]), (shifted[1:], abuf[1:])):     # k_policy
         assert (wv.data_ptr() % 16 != 0) or (av.data_ptr() % 2 != 0)
         abuf.zero_()
         _native.check(env.L.tarok_policy_random(env._h, env._p(wv), env._p(av), env._stream()))
-        assert (av.cpu().numpy() == want).all()
+        assert (av.cpu().numpy() == got).all()
     env.close()
 
 
