@@ -98,8 +98,11 @@ void tarok_destroy(tarok_env *env);
 int64_t tarok_num_games(const tarok_env *env);
 
 /* Launch tuning of an env; the results never depend on it.  Defaults from the batch size at tarok_create.
- *   TAROK_OPT_REFILL_FAN  1..8 play workgroups whose refill lists one refill workgroup works off */
+ *   TAROK_OPT_REFILL_FAN   1..8 play workgroups whose refill lists one refill workgroup works off
+ *   TAROK_OPT_LAZY_REFILL  0/1  tarok_step / tarok_step_random: the next-game lines their slots empty are dealt in bulk
+ *                               every sixteenth launch instead of in the launch after (default: on below 2^20 games) */
 #define TAROK_OPT_REFILL_FAN 2
+#define TAROK_OPT_LAZY_REFILL 3
 int tarok_set_option(tarok_env *env, int option, int value);
 
 /* Deal and set up every game: Igra.razdeli (Igra.py:65-73) + the contract

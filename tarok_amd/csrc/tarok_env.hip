@@ -42,7 +42,8 @@
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 // list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
 // different XCDs, whose L2s are not coherent: two of them must never write into one line
-#define TK_RC(group, par) ((((size_t)(group)) * 2 + (par)) * 32)
+#define TK_RC(group, k) ((((size_t)(group)) * 4 + (k)) * 32)     // k = 0, 1: the per-launch lists by parity; 2, 3: the one-card step's stretch lists
+#define TK_BULK_CAP (4 * TK_BLOCK)  // entries of a stretch list: a slot ends at most four games in TK_BULK_EVERY = 16 one-card launches
 
 #ifndef TK_AHEAD
 #define TK_AHEAD TAROK_GAMES_AHEAD  // next-game lines per slot (<= 15: epar and cprev are 4 bits each)
@@ -105,10 +106,12 @@ struct tarok_env {
     u64 *gkey;               // RNG key of the slot's current game
     uint8_t *hist;           // [48][n] play history (card p of the slot's current game), TAROK_HISTORY envs only
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
-    u32 *rcount;             // [play workgroups][2]
+    u32 *rcount;             // [play workgroups][4] list lengths, one 128-byte line each (TK_RC)
+    u64 *elist;              // the one-card step's stretch lists [play workgroups][2][TK_BULK_CAP] (refill_role)
     u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
                              // launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
+    uint32_t lazy_refill;    // the one-card step lists emptied lines for a bulk deal every TK_BULK_EVERY launches (refill_role)
     int n_cus;               // compute units of the device (k_learn_dw's grid), 0 = not asked yet
     float *adam_sumsq;       // k_learn_gnorm's partial sums
     u64 *stamps;             // diagnostics only
@@ -325,28 +328,47 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy_x4(int64_t n, const u64 *__
     }
 }
 
-// Launch parity (see the file header) without a host counter.  The workgroups of step launches are counted
-// as they START, modulo twice their number G per launch (every step launch of an env has the same grid):
-// launch L begins with the count at (L mod 2) * G; every workgroup reads the count together with its first
-// loads (launch_count: nothing waits for it alone) and adds itself afterwards (launch_counted: a wrapping
-// increment WITHOUT a return value, issued once the read has returned — it completes somewhere under the
-// card loop).  At any read at most G - 1 workgroups of the running launch have added themselves, so the
-// count is still in launch L's half: parity = "count >= G".  The kernel boundary drains the adds before
-// the next launch reads.  The count is kept in TK_EPOCH_SHARDS separate counters (one 128-byte line each),
-// workgroup b using counter b mod TK_EPOCH_SHARDS with G_s = the number of such workgroups: the argument
-// holds for every counter on its own, and the adds do not queue up behind each other — ONE counter took
-// 512 same-address atomics per launch at 65,536 games, serialised at the memory side: +3.4 us on every
-// launch, wherever in the kernel they were issued (profiles/r02_ab_launch_parity.txt).
+// Launch number modulo TK_PHASES (see the file header) without a host counter.  The workgroups of step launches are
+// counted as they START, modulo TK_PHASES times their number G per launch (every step launch of an env has the same
+// grid): launch L begins with the count at (L mod TK_PHASES) * G; every workgroup reads the count together with its
+// first loads (launch_count: nothing waits for it alone) and adds itself afterwards (launch_counted: a wrapping
+// increment WITHOUT a return value, behind the read in the lane's program order — it completes somewhere under the
+// card loop).  At any read at most G - 1 workgroups of the running launch have added themselves, so the count is still
+// in launch L's band: phase = count / G.  The kernel boundary drains the adds before the next launch reads.  The
+// count is kept in TK_EPOCH_SHARDS separate counters (one 128-byte line each), workgroup b using counter b mod
+// TK_EPOCH_SHARDS with G_s = the number of such workgroups: the argument holds for every counter on its own, and the
+// adds do not queue up behind each other — ONE counter took 512 same-address atomics per launch at 65,536 games,
+// serialised at the memory side: +3.4 us on every launch, wherever in the kernel they were issued
+// (profiles/r02_ab_launch_parity.txt).
+// The low bit of the phase is the parity of the refill list the launch writes; the one-card step also works the
+// next-game lines its slots emptied off in bulk, once per TK_BULK_EVERY launches (step_role, refill_role).
 #define TK_EPOCH_SHARDS 256
+#define TK_PHASES 32u
+#define TK_BULK_EVERY 16u
 __device__ __forceinline__ u32 launch_shard_size() {      // workgroups of this grid that share this workgroup's counter
     return (gridDim.x + TK_EPOCH_SHARDS - 1 - (blockIdx.x % TK_EPOCH_SHARDS)) / TK_EPOCH_SHARDS;
 }
 __device__ __forceinline__ u32 launch_count(const u32 *epoch) {
     return __hip_atomic_load(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ u32 launch_parity(u32 count) { return count >= launch_shard_size() ? 1u : 0u; }
-__device__ __forceinline__ void launch_counted(u32 *epoch) {          // call after launch_count's value has arrived
-    if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), 2u * launch_shard_size() - 1u);
+// count / G_s: a float estimate (count < TK_PHASES * G_s is exact as a float for any grid a launch can have; the half added
+// to the count keeps the quotient away from the integers) put right by one exact integer step either way
+__device__ __forceinline__ u32 launch_phase(u32 count) {
+    // (the count is the same in every lane, and the compiler knows: without this fence it moves the quotient — and the wait
+    // for the count's load — to the top of the kernel, ahead of the state loads: +4 us per launch at 4 M games)
+    asm volatile("" : "+v"(count));
+    u32 g = launch_shard_size();
+    u32 q = (u32)(((float)count + 0.5f) * __builtin_amdgcn_rcpf((float)g));
+    q -= (q * g > count) ? 1u : 0u;
+    q += ((q + 1u) * g <= count) ? 1u : 0u;
+    return q;
+}
+__device__ __forceinline__ u32 launch_parity(u32 count) { return launch_phase(count) & 1u; }
+// call after launch_count in program order — one lane's read and add of one address stay in that order — and before the
+// first use of its value: the add counts as an outstanding memory operation of the wave, and issued only once the
+// count has arrived it adds a memory-side round trip to the life of every step wave (+4 us per launch at 4 M games)
+__device__ __forceinline__ void launch_counted(u32 *epoch) {
+    if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), TK_PHASES * launch_shard_size() - 1u);
 }
 
 // The step kernels.  One launch plays `cards` cards of every game:
@@ -370,32 +392,75 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {          // call af
 // smaller fan: a refill workgroup that needs a second pass would outlast the play.
 // `count` = launch_count()'s value, possibly still in flight: the list lengths of BOTH parities are requested
 // before it is looked at, so the parity costs this role no memory round trip of its own.
+// BULK (k_step): the lines the one-card step's slots emptied are NOT on those lists.  Every slot is at the same card of
+// its trick and games end on a trick's 4th card, so they would all be dealt in the launch after it, whose refill
+// workgroups (a wave alone issues an instruction every ~4.5 cycles, a deal is 2.7k of them) outlast the step
+// workgroups: 9.9 us against 4.3 at 65,536 games, 79 against 44 at 4 M (profiles/r03_step_durations.txt,
+// r03_ab_step.txt (e)).  A slot has fourteen lines and takes at most four in sixteen launches, so step_role collects
+// those entries in a second pair of lists per workgroup, switched every TK_BULK_EVERY launches, and the first launch
+// of each such stretch works the previous stretch's list off here, on dense lanes, in one go.  A line waits for its
+// deal at most TK_BULK_EVERY launches and is not needed again before thirteen more games of its slot have
+// ended (>= 52 launches); lines a slot must not meet half written — the fourteen of a slot that dealt a game in place —
+// stay on the per-launch lists.  !BULK (k_play_wide, k_policy_step: slots there can take a line per trick): the
+// stretch lists of the workgroup's groups are emptied unworked — those lines stay stale until their slot comes round
+// to them, deals that game in place and lists all fourteen.
+template <bool BULK>
 __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
                                         u32 count, u32 *epoch, u32 fan, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
-                                        const u32 *__restrict__ rcount) {
+                                        u32 *__restrict__ rcount, const u64 *__restrict__ elist) {
     u32 g0 = rblock * fan;
-    u32 len[2][TK_REFILL_FAN];
+    u32 len0[TK_REFILL_FAN], len1[TK_REFILL_FAN];
 #pragma unroll
     for (u32 q = 0; q < TK_REFILL_FAN; q++) {
         bool has = q < fan && g0 + q < play_groups;
-        len[0][q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
-        len[1][q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
+        len0[q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
+        len1[q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
     }
-    u32 par = launch_parity(count);
     launch_counted(epoch);
+    u32 phase = launch_phase(count), par = phase & 1u;
+    if (!BULK) {                 // empty the stretch lists
+        if (tid < 2 * fan && g0 + tid / 2 < play_groups) rcount[TK_RC(g0 + tid / 2, 2 + (tid & 1))] = 0u;
+    }
     u32 cum[TK_REFILL_FAN + 1];
     cum[0] = 0;
+    const u32 odd = 0u - par;    // (a mask, not a select between the arrays: that becomes a parity-indexed array in scratch)
 #pragma unroll
-    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + (par ? len[0][q] : len[1][q]);
-    for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
-        u32 q = 0;
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + ((len0[q] & odd) | (len1[q] & ~odd));
+    const bool any = cum[TK_REFILL_FAN] != 0;                 // (the same in every thread: nobody writes these lengths in this launch)
+    // the lists of the workgroup's groups, one after the other, entry j on thread j mod nthreads; BULK: a second pass (the
+    // same code: one copy of the deal) over the stretch lists in the launches that work them off
+    const u64 *lists = rlist;
+    u32 which = par ^ 1u, cap = TK_REFILL_CAP;
+#pragma nounroll
+    for (u32 pass = 0; pass < (BULK ? 2u : 1u); pass++) {
+        if (pass == 1) {
+            if (phase % TK_BULK_EVERY != 0) break;
+            which = ((phase / TK_BULK_EVERY) & 1u) ^ 1u;     // the stretch before this one
+            lists = elist; cap = TK_BULK_CAP;
 #pragma unroll
-        for (u32 r = 1; r < TK_REFILL_FAN; r++) q += j >= cum[r] ? 1u : 0u;
-        u32 base = 0;
+            for (u32 q = 0; q < TK_REFILL_FAN; q++) {
+                bool has = q < fan && g0 + q < play_groups;
+                cum[q + 1] = cum[q] + (has ? min(rcount[TK_RC(g0 + q, 2 + which)], (u32)TK_BULK_CAP) : 0u);
+            }
+        }
+        for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
+            u32 q = 0;
 #pragma unroll
-        for (u32 r = 0; r < TK_REFILL_FAN; r++) base = (r == q) ? cum[r] : base;
-        u64 en = rlist[((int64_t)(g0 + q) * 2 + (par ^ 1)) * TK_REFILL_CAP + (j - base)];
-        deal_into_buffer(aux, (int64_t)(g0 + q) * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
+            for (u32 r = 1; r < TK_REFILL_FAN; r++) q += j >= cum[r] ? 1u : 0u;
+            u32 base = 0;
+#pragma unroll
+            for (u32 r = 0; r < TK_REFILL_FAN; r++) base = (r == q) ? cum[r] : base;
+            u64 en = lists[((int64_t)(g0 + q) * 2 + which) * cap + (j - base)];
+            deal_into_buffer(aux, (int64_t)(g0 + q) * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
+        }
+    }
+    // the lengths worked off are cleared (the one-card step's workgroups write a length only when they list something);
+    // every thread has had its copies (cum[]) before the barrier
+    const bool bulk = BULK && phase % TK_BULK_EVERY == 0;
+    if (any || bulk) {
+        __syncthreads();
+        if (any && tid < fan && g0 + tid < play_groups) rcount[TK_RC(g0 + tid, par ^ 1u)] = 0u;
+        if (bulk && tid < fan && g0 + tid < play_groups) rcount[TK_RC(g0 + tid, 2 + which)] = 0u;
     }
 }
 
@@ -849,7 +914,7 @@ template <bool HIST>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
-        refill_role(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
+        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, nullptr);
     else {
 #ifdef TK_PLAY_PRIO                          // diagnostics build: wave priority of the play role (no effect: profiles/r02_ab_lone_wave_rewrite.txt)
         __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
@@ -910,18 +975,25 @@ __device__ __forceinline__ void deal_in_place_wave(bool deal_here, Game &gd, u64
 // the lanes of such a launch — issue them speculatively next to the state load: 5.3 B/step more read traffic at
 // 4 M games, and no faster at any batch size, 65,536 games included (profiles/r03_ab_step.txt).
 #define FINQ_WORDS 13
-template <bool RANDOM>
+template <bool RANDOM, bool LAZY>
 __device__ __forceinline__ void step_role(
-    u32 group, u32 tid, bool active, u32 a_reg,
+    u32 group, u32 tid, bool active, u32 a_reg, bool lazy_on,
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 count, u32 *epoch,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u32 (*__restrict__ finq)[TK_BLOCK] /* LDS [FINQ_WORDS][TK_BLOCK] */) {
+    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ elist,
+    u32 (*__restrict__ finq)[TK_BLOCK] /* LDS [FINQ_WORDS][TK_BLOCK] */) {
     __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
     __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
-    __shared__ u32 push_count, fin_count;
-    if (tid == 0) { push_count = 0; fin_count = 0; }
+    __shared__ u32 push_count, fin_count, late_count;
+    __shared__ u64 late_list[LAZY ? TK_BLOCK : 1];        // LAZY: entries for the stretch list (refill_role), one per slot at most
+    const bool lazy = LAZY && lazy_on;                    // (LAZY: the kernel has the stretch lists at all; lazy_on: this env uses them)
+    if (tid == 0) { push_count = 0; fin_count = 0; late_count = 0; }
+    // (lazy) how full the two stretch lists of this group are: asked for now by every thread (one address per workgroup),
+    // looked at when the launch's entries go out — no broadcast, no barrier of its own
+    u32 efill0 = 0, efill1 = 0;
+    if (lazy) { efill0 = rcount[TK_RC(group, 2)]; efill1 = rcount[TK_RC(group, 3)]; }
     __syncthreads();
     int64_t i = (int64_t)group * TK_BLOCK + tid;
     bool valid = active && i < n;
@@ -952,8 +1024,7 @@ __device__ __forceinline__ void step_role(
             }
         }
     };
-    const u32 par = launch_parity(count);    // (`count` was requested before the state: it has arrived with it)
-    launch_counted(epoch);
+    launch_counted(epoch);                   // (issued BEFORE the count is waited for: its round trip runs beside the state's)
     g.cprev = 0;
     // ---- the card: krog's body (Klop.py:47-79, Navadna_igra.py:115-141), apply_step
     const bool play = valid && g.phase == TK_PHASE_PLAY;
@@ -999,8 +1070,11 @@ __device__ __forceinline__ void step_role(
         TK_STREAM_STORE(&obs[i], obs_word(g, fin));
         if (done) TK_STREAM_STORE(&done[i], (uint8_t)(fin ? 1 : 0));
     }
-    // ---- state back; the refill list of this launch (see play_role)
-    const u32 np = resync ? (u32)TK_AHEAD : consumed;
+    // ---- state back; the refill list of this launch (see play_role).  LAZY: the one line a slot emptied by taking its next
+    // game goes on the group's stretch list instead (refill_role: dealt in bulk, up to TK_BULK_EVERY launches later; nothing
+    // of this slot is re-dealt during the next launch, so `cprev` stays 0); only a slot that dealt a game in place lists
+    // its fourteen lines for the next launch, as play_role does
+    const u32 np = resync ? (u32)TK_AHEAD : (lazy ? 0u : consumed);
     if (valid) {
         g.cprev = np;                        // the next launch must not read those lines
         if (consumed) { cnt[i].episode = cur_ep; gkey[i] = key; }
@@ -1011,6 +1085,7 @@ __device__ __forceinline__ void step_role(
         push_ep[tid] = cur_ep;
         for (u32 j = 0; j < np; j++) push_list[p0 + j] = (unsigned short)(j * TK_BLOCK + tid);
     }
+    if (lazy && valid && consumed && !resync) late_list[atomicAdd(&late_count, 1u)] = ((u64)(cur_ep + TK_AHEAD) << 32) | tid;
     __syncthreads();
     // ---- the games that ended with this card, scored one per lane: final_scores from the final state alone
     // (Klop.py:36-45, Berac.py:33-44, Navadna_igra.py:80-113); reward row and score sums of the slot
@@ -1040,22 +1115,38 @@ __device__ __forceinline__ void step_role(
             cnt[it].score_sum = make_int4((int)finq[9][e] + (int16_t)(sc & 0xFFFF), (int)finq[10][e] + (int16_t)((sc >> 16) & 0xFFFF),
                                           (int)finq[11][e] + (int16_t)((sc >> 32) & 0xFFFF), (int)finq[12][e] + (int16_t)(sc >> 48));
         }
-    u32 total = push_count;
-    u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
-    if (active)
-        for (u32 j = tid; j < total; j += TK_BLOCK) {              // list entry: episode to deal << 32 | slot in group
-            u32 en = push_list[j], t = en % TK_BLOCK;
-            lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
-        }
-    if (tid == 0) rcount[TK_RC(group, par)] = total;
+    // ---- the lists: nothing to write in most launches (the refill roles clear the lengths they have worked off), and then
+    // the launch's number is not even worked out
+    const u32 total = push_count, late = lazy ? late_count : 0u;
+    if ((total | late) == 0) return;
+    const u32 phase = launch_phase(count), par = phase & 1u;    // (`count` was requested before the state: it arrived with it)
+    if (total) {
+        u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
+        if (active)
+            for (u32 j = tid; j < total; j += TK_BLOCK) {          // list entry: episode to deal << 32 | slot in group
+                u32 en = push_list[j], t = en % TK_BLOCK;
+                lst[j] = ((u64)(push_ep[t] + TK_AHEAD - en / TK_BLOCK) << 32) | t;
+            }
+        if (tid == 0) rcount[TK_RC(group, par)] = total;
+    }
+    if (lazy && late) {
+        const u32 eb = (phase / TK_BULK_EVERY) & 1u;       // this stretch's list; entries beyond its capacity are dropped (never:
+        const u32 fill = eb ? efill1 : efill0;             // a slot ends at most four games in a stretch; a dropped line would
+        u64 *el = elist + ((int64_t)group * 2 + eb) * TK_BULK_CAP;          // just stay stale)
+        if (active && tid < late && fill + tid < TK_BULK_CAP) el[fill + tid] = late_list[tid];
+        if (tid == 0) rcount[TK_RC(group, 2 + eb)] = min(fill + late, (u32)TK_BULK_CAP);
+    }
 }
 
 #define TK_STEP_ARGS                                                                                                              \
-    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,                                    \
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan, u32 lazy,                          \
         const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
         ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
-        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount
+        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ elist
+#ifndef TK_STEP_LAZY
+#define TK_STEP_LAZY true          // (false: diagnostic build, every emptied line on the per-launch lists as in k_play_wide)
+#endif
 #ifndef TK_STEP_WAVES
 #define TK_STEP_WAVES 4            // waves per SIMD the one-card kernel is compiled for (diagnostic builds: 5, 6, 8)
 #endif
@@ -1069,10 +1160,10 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STE
     __shared__ u32 finq[FINQ_WORDS][TK_BLOCK];
     u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
     if (r == 0)
-        refill_role(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
+        refill_role<TK_STEP_LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, elist);
     else
-        step_role<RANDOM>(blockIdx.x - q - 1, threadIdx.x, true, 255u, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
-                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, finq);
+        step_role<RANDOM, TK_STEP_LAZY>(blockIdx.x - q - 1, threadIdx.x, true, 255u, lazy != 0, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
+                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -1950,7 +2041,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
     u32 count = launch_count(epoch);          // (in flight under the policy's first loads)
     if (blockIdx.x >= play_groups) {
-        refill_role(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount);
+        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, nullptr);
         return;
     }
     __shared__ uint8_t act_s[2 * PM_M];
@@ -1959,8 +2050,8 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
                    act_s, &lds);
     __syncthreads();                          // (the policy's LDS is free from here on: the step's scoring list goes there)
     u32 tid = threadIdx.x;
-    step_role<false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], n, seed, offset, mix, flags,
-                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount,
+    step_role<false, false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], false, n, seed, offset, mix, flags,
+                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr,
                            reinterpret_cast<u32 (*)[TK_BLOCK]>(lds));
 }
 
@@ -2164,6 +2255,10 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->device = device; e->n = n_games; e->offset = game_offset; e->seed = seed; e->mix = mix; e->flags = flags;
     // latency-bound batches keep refill workgroups single-pass; throughput-bound ones pack them dense
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
+    // Bulk deals where a launch is a handful of workgroups per CU and its refill workgroups' deals are its tail (65,536
+    // games: -8 % per lock-step, 262,144: -7 %); where the batch streams the deals' instructions add to the launch
+    // wherever they run, and sixteen launches' worth at once cost what they cost one trick at a time (profiles/r03_ab_step.txt (e))
+    e->lazy_refill = n_games < (1 << 20) ? 1 : 0;
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMalloc((void **)&e->s23, (size_t)n_games * sizeof(ulonglong2));
@@ -2176,6 +2271,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     size_t groups = (size_t)((n_games + TK_BLOCK - 1) / TK_BLOCK);
     if (r == hipSuccess) r = hipMalloc((void **)&e->rlist, groups * 2 * TK_REFILL_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->elist, groups * 2 * TK_BULK_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->adam_sumsq, 1024 * sizeof(float));
     if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 32 * TK_EPOCH_SHARDS * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32));
@@ -2202,7 +2298,7 @@ void tarok_destroy(tarok_env *e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
-    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->epoch); (void)hipFree(e->hist); (void)hipFree(e->adam_sumsq);
+    (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->elist); (void)hipFree(e->epoch); (void)hipFree(e->hist); (void)hipFree(e->adam_sumsq);
     delete e;
 }
 
@@ -2211,6 +2307,7 @@ int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
 int tarok_set_option(tarok_env *e, int option, int value) {
     if (!e) return TAROK_EINVAL;
     if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) e->refill_fan = (uint32_t)value;
+    else if (option == TAROK_OPT_LAZY_REFILL && (value == 0 || value == 1)) e->lazy_refill = (uint32_t)value;
     else return TAROK_EINVAL;
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }      // (the cached graph holds the old launches)
     return TAROK_OK;
@@ -2274,8 +2371,8 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     if (cards == 1) {
 #define TK_LAUNCH_STEP(R)                                                                                                \
     hipLaunchKernelGGL((k_step<R>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
-                       fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
-                       e->gkey, e->rlist, e->rcount)
+                       fan, e->lazy_refill, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
+                       e->gkey, e->rlist, e->rcount, e->elist)
         if (random) TK_LAUNCH_STEP(true); else TK_LAUNCH_STEP(false);
 #undef TK_LAUNCH_STEP
         return;

@@ -54,9 +54,9 @@ class Obs:
 
 
 class TarokVecEnv:
-    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False, refill_fan=None):
-        """refill_fan: launch tuning (tarok_set_option; None = the library's default for the batch size);
-        results never depend on it."""
+    def __init__(self, n_games, device=0, seed=0, mix=K.MIX_ALL, game_offset=0, history=False, refill_fan=None, lazy_refill=None):
+        """refill_fan, lazy_refill: launch tuning (tarok_set_option; None = the library's default for the batch size);
+        results never depend on them."""
         self._h = None
         L = _native.lib()
         if not torch.cuda.is_available() or L.tarok_device_count() == 0:
@@ -76,6 +76,10 @@ class TarokVecEnv:
             refill_fan = int(os.environ["TAROK_REFILL_FAN"])
         if refill_fan is not None:
             _native.check(L.tarok_set_option(h, K.OPT_REFILL_FAN, int(refill_fan)))
+        if lazy_refill is None and os.environ.get("TAROK_LAZY_REFILL"):
+            lazy_refill = int(os.environ["TAROK_LAZY_REFILL"])
+        if lazy_refill is not None:
+            _native.check(L.tarok_set_option(h, K.OPT_LAZY_REFILL, int(lazy_refill)))
         with torch.cuda.device(self.device):
             self.obs_words = torch.zeros(self.n, dtype=torch.int64, device=self.device)
             self.reward = torch.zeros((self.n, 4), dtype=torch.int16, device=self.device)

@@ -44,6 +44,7 @@ CLEAR_COUNTERS = 4
 REWARD_REF = 8           # step: reward_out = what rezultat_igre folds into the last transition (Igralec.py:421-437)
 HISTORY = 16             # TarokVecEnv(history=True): keep the play history (needed by observe_ref)
 OPT_REFILL_FAN = 2        # tarok_set_option
+OPT_LAZY_REFILL = 3
 GAMES_AHEAD = 14          # TAROK_GAMES_AHEAD: games every slot keeps dealt ahead for auto-reset
 # the flat parameter vector of the 256-256-256-64 policy (include/tarok_env.h TAROK_MLP_*)
 MLP_W1, MLP_B1, MLP_W2, MLP_B2, MLP_W3, MLP_B3, MLP_PARAMS = 0, 65536, 65792, 131328, 131584, 147968, 148032

@@ -298,16 +298,19 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
     # fan: refill lists per refill workgroup (tarok_set_option; None = the default for the size, 1)
     # (the bench's own launch shape, 128 cards x 65,536 games, is test_bench_launch_shape_vs_oracle)
-    for cards, chunk, pf, fan in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
+    # lazy: the one-card step's emptied lines dealt in bulk every sixteenth launch (tarok_set_option; the default below 2^20
+    # games) or in the launch after (0)
+    for cards, chunk, pf, fan, *lazy in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
                                   (0, 48, 0, 8), (1, 64, 0, 3), (1, 0, 16, 8), (0, 96, 0, 4),
+                                  (0, 48, 0, 8, 0), (1, 64, 0, 3, 0), (1, 0, 16, None, 0), (0, 96, 4, 4, 0), (1, 0, 0, 2, 0),
                                   (4, 48, 8, None), (4, 0, 4, None), (8, 96, 8, None), (16, 192, 16, None), (3, 48, 12, None), (48, 192, 48, None),
                                   (4, 64, 0, None), (8, 64, 0, 5), (12, 48, 0, None),
                                   (24, 192, 0, None), (24, 96, 0, None), (32, 192, 0, None), (48, 192, 0, None), (48, 96, 0, None)]:
-        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, refill_fan=fan)
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, refill_fan=fan, lazy_refill=lazy[0] if lazy else None)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=chunk, auto_reset=True, prefetch_every=pf)
         ep, ss = env.counters()
-        cfg = (cards, chunk, pf, fan)
+        cfg = (cards, chunk, pf, fan, lazy)
         assert (ep == ref["episode"]).all(), cfg
         assert (ss == ref["score_sum"]).all(), cfg
         assert (env.state() == ref["lanes"]).all(), cfg
@@ -322,15 +325,15 @@ def test_step_api_streaming_size_vs_oracle(T, O, S):
     canonical state and observation word."""
     n, seed, steps = 1 << 20, 9, 96
     ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
-    for cards in (0, 1):
-        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    for cards, lazy in ((0, None), (1, None), (1, 1)):         # (lazy: bulk deals every sixteenth launch — off by default at this size)
+        env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=48, auto_reset=True)
         ep, ss = env.counters()
-        assert (ep == ref["episode"]).all(), cards
-        assert (ss == ref["score_sum"]).all(), cards
-        assert (env.state() == ref["lanes"]).all(), cards
-        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), cards
+        assert (ep == ref["episode"]).all(), (cards, lazy)
+        assert (ss == ref["score_sum"]).all(), (cards, lazy)
+        assert (env.state() == ref["lanes"]).all(), (cards, lazy)
+        assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all(), (cards, lazy)
         env.close()
 
 
@@ -990,11 +993,14 @@ def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S
     part.close()
 
 
-def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S):
+@pytest.mark.parametrize("lazy", [None, 0])
+def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S, lazy):
     """Graph replays, eager one-card steps, tricks, the two-kernel path and a mid-run reset, mixed
-    (odd launch counts between graphs exercise the parity flush): still the oracle's games."""
+    (odd launch counts between graphs exercise the parity flush): still the oracle's games.  lazy (the default at
+    this size): the one-card launches collect the lines they empty for a bulk deal every sixteenth launch; launches of
+    the multi-card kernel in between drop what was collected."""
     n, seed = 20000, 41
-    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
     env.reset()
     steps = 0
     env.run_random(96, cards_per_launch=4, graph_chunk=48, auto_reset=True); steps += 96
@@ -1088,20 +1094,21 @@ def test_fused_policy_mlp_kernel_vs_torch(T, S):
     env.close()
 
 
-@pytest.mark.parametrize("mixname,fan", [("all", None), ("berac", None), ("berac", 3)])
-def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname, fan):
+@pytest.mark.parametrize("mixname,fan,lazy", [("all", None, None), ("berac", None, None), ("berac", 3, None), ("all", None, 0), ("berac", 3, 0)])
+def test_random_api_sequences_against_an_oracle_model(T, O, S, mixname, fan, lazy):
     """Model-based fuzz: a random sequence of API calls (one-card steps with legal / illegal /
     garbage cards, in-kernel-policy steps, 1..48 cards per launch, auto-reset on and off, resets)
     on the GPU env vs the same sequence applied slot by slot to the CPU oracle; canonical state,
     observation words, episode numbers and score sums compared after every call.  The all-Berac
     mix makes slots finish several games inside one launch (swap-ins from more than one
     next-game line, lines on a refill list, games dealt in place).  fan: refill lists per refill workgroup
-    (three lists of a 768-slot env: one refill workgroup among three play workgroups)."""
+    (three lists of a 768-slot env: one refill workgroup among three play workgroups); lazy: the one-card step's bulk deals
+    (the default at this size) or per-launch lists (0)."""
     import ctypes as C
     rnd = np.random.RandomState(12345)
     n, seed, mix = 768, 77, (S.MIX_ALL if mixname == "all" else S.MIX_FIXED + 7)
     L = O.lib()
-    env = T.TarokVecEnv(n, seed=seed, mix=mix, refill_fan=fan)
+    env = T.TarokVecEnv(n, seed=seed, mix=mix, refill_fan=fan, lazy_refill=lazy)
 
     class Slot:
         pass

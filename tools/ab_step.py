@@ -15,7 +15,7 @@ env = TarokVecEnv(n, seed=0, mix=K.MIX_ALL)
 out = {}
 for cards, name in ((0, "two"), (1, "random")):
     env.reset()
-    steps = 960 if n <= (1 << 20) else 384
+    steps = int(os.environ.get("AB_STEPS", 960 if n <= (1 << 20) else 384))
     env.run_random(192, cards_per_launch=cards, graph_chunk=192, auto_reset=True)
     best = 1e9
     for rep in range(3):
