@@ -16,10 +16,12 @@
 // trick 1, is 4 cards: with fourteen lines launches of 128 cards (32 tricks; a slot starts ~3.5 games
 // in one) practically never wait for a deal (with seven, round 1, 64 cards were the limit: a slot that
 // finishes more games within two launches than it has lines deals in place, and the launch is its
-// slowest wave).  Lists are double-buffered by launch parity — kept in DEVICE memory
-// as a count of started workgroups that every step launch advances by its grid size (launch_count /
-// launch_counted), so eager launches and replays of captured graphs (the library's own or a caller's,
-// e.g. torch.cuda.graph) mix freely and in any number.  A line is valid iff its episode tag matches
+// slowest wave).  Lists are double-buffered by launch parity — the low bit of the launch number, which is kept
+// modulo 32 in DEVICE memory as a count of started workgroups that every step launch advances by its grid size
+// (launch_count / launch_counted / launch_phase), so eager launches and replays of captured graphs (the library's
+// own or a caller's, e.g. torch.cuda.graph) mix freely and in any number.  The one-card step of small batches does
+// not deal the lines it empties in the next launch at all but collects them for a bulk deal every sixteenth launch
+// (refill_role<true>, TAROK_OPT_LAZY_REFILL).  A line is valid iff its episode tag matches
 // and it is not being re-dealt right now (`cprev` in the slot's state), and a slot that ever runs
 // out of usable lines just deals the game itself, wave-cooperatively (ballot/readlane), same result.
 #include "tarok_device.h"
