@@ -408,42 +408,40 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {
 // to them, deals that game in place and lists all fourteen.
 template <bool BULK>
 __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
-                                        u32 count, u32 *epoch, u32 fan, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
+                                        u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
                                         u32 *__restrict__ rcount, const u64 *__restrict__ elist) {
     u32 g0 = rblock * fan;
-    u32 len0[TK_REFILL_FAN], len1[TK_REFILL_FAN];
-#pragma unroll
-    for (u32 q = 0; q < TK_REFILL_FAN; q++) {
-        bool has = q < fan && g0 + q < play_groups;
-        len0[q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
-        len1[q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
-    }
+    // all four list lengths of the workgroup's (up to eight) groups with ONE load per wave: lane 4 q + k holds length k of
+    // group g0 + q; they are handed round with v_readlane (a refill wave with nothing to do — most of them, in most
+    // launches — costs a launch as much wave-slot time as a step wave: sixteen loads behind sixteen tests were a fifth of it)
+    const u32 lane = tid & 63u;
+    const bool mine_has = lane < 4 * TK_REFILL_FAN && (lane >> 2) < fan && g0 + (lane >> 2) < play_groups;
+    const u32 mine = mine_has ? rcount[TK_RC(g0 + (lane >> 2), lane & 3u)] : 0u;
     launch_counted(epoch);
-    u32 phase = launch_phase(count), par = phase & 1u;
+    const u32 phase = (u32)__builtin_amdgcn_readfirstlane((int)launch_phase(count)), par = phase & 1u;   // (a scalar: it selects lanes below)
     if (!BULK) {                 // empty the stretch lists
         if (tid < 2 * fan && g0 + tid / 2 < play_groups) rcount[TK_RC(g0 + tid / 2, 2 + (tid & 1))] = 0u;
     }
     u32 cum[TK_REFILL_FAN + 1];
     cum[0] = 0;
-    const u32 odd = 0u - par;    // (a mask, not a select between the arrays: that becomes a parity-indexed array in scratch)
+    u32 which = par ^ 1u;
 #pragma unroll
-    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + ((len0[q] & odd) | (len1[q] & ~odd));
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + (u32)__builtin_amdgcn_readlane((int)mine, (int)(4 * q + which));
     const bool any = cum[TK_REFILL_FAN] != 0;                 // (the same in every thread: nobody writes these lengths in this launch)
     // the lists of the workgroup's groups, one after the other, entry j on thread j mod nthreads; BULK: a second pass (the
     // same code: one copy of the deal) over the stretch lists in the launches that work them off
     const u64 *lists = rlist;
-    u32 which = par ^ 1u, cap = TK_REFILL_CAP;
+    u32 cap = TK_REFILL_CAP;
+    const bool bulk = BULK && bulk_on && phase % TK_BULK_EVERY == 0;      // (bulk_on: the env's step workgroups fill stretch lists)
 #pragma nounroll
     for (u32 pass = 0; pass < (BULK ? 2u : 1u); pass++) {
         if (pass == 1) {
-            if (phase % TK_BULK_EVERY != 0) break;
+            if (!bulk) break;
             which = ((phase / TK_BULK_EVERY) & 1u) ^ 1u;     // the stretch before this one
             lists = elist; cap = TK_BULK_CAP;
 #pragma unroll
-            for (u32 q = 0; q < TK_REFILL_FAN; q++) {
-                bool has = q < fan && g0 + q < play_groups;
-                cum[q + 1] = cum[q] + (has ? min(rcount[TK_RC(g0 + q, 2 + which)], (u32)TK_BULK_CAP) : 0u);
-            }
+            for (u32 q = 0; q < TK_REFILL_FAN; q++)
+                cum[q + 1] = cum[q] + min((u32)__builtin_amdgcn_readlane((int)mine, (int)(4 * q + 2 + which)), (u32)TK_BULK_CAP);
         }
         for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
             u32 q = 0;
@@ -458,11 +456,10 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     }
     // the lengths worked off are cleared (the one-card step's workgroups write a length only when they list something);
     // every thread has had its copies (cum[]) before the barrier
-    const bool bulk = BULK && phase % TK_BULK_EVERY == 0;
     if (any || bulk) {
         __syncthreads();
         if (any && tid < fan && g0 + tid < play_groups) rcount[TK_RC(g0 + tid, par ^ 1u)] = 0u;
-        if (bulk && tid < fan && g0 + tid < play_groups) rcount[TK_RC(g0 + tid, 2 + which)] = 0u;
+        if (bulk && tid < fan && g0 + tid < play_groups) rcount[TK_RC(g0 + tid, 2 + which)] = 0u;     // (which: the stretch list's, after the second pass)
     }
 }
 
@@ -916,7 +913,7 @@ template <bool HIST>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
-        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, nullptr);
+        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
     else {
 #ifdef TK_PLAY_PRIO                          // diagnostics build: wave priority of the play role (no effect: profiles/r02_ab_lone_wave_rewrite.txt)
         __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
@@ -1162,7 +1159,7 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STE
     __shared__ u32 finq[FINQ_WORDS][TK_BLOCK];
     u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
     if (r == 0)
-        refill_role<TK_STEP_LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, elist);
+        refill_role<TK_STEP_LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, lazy != 0, aux, rlist, rcount, elist);
     else
         step_role<RANDOM, TK_STEP_LAZY>(blockIdx.x - q - 1, threadIdx.x, true, 255u, lazy != 0, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
                                 reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
@@ -2043,7 +2040,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
     u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
     u32 count = launch_count(epoch);          // (in flight under the policy's first loads)
     if (blockIdx.x >= play_groups) {
-        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, aux, rlist, rcount, nullptr);
+        refill_role<false>(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
         return;
     }
     __shared__ uint8_t act_s[2 * PM_M];

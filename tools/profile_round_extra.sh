@@ -13,7 +13,14 @@ for m in random two; do
   python3 tools/step_durations.py $OUT/dur_$m 4194304 >> $OUT/step_durations_final.txt
   rm -rf $OUT/dur_$m
 done
+# 65,536 games: the one-card step deals in bulk every sixteenth launch there (period 16: launch number mod 16, 0 = the bulk launch)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/dur_small -- python3 tools/step_ledger.py 65536 two d 0 1 176 > $OUT/dur_small.log 2>&1
+echo "65,536 games, by launch number mod 16:" >> $OUT/step_durations_final.txt
+python3 tools/step_durations.py $OUT/dur_small 65536 16 >> $OUT/step_durations_final.txt
+rm -rf $OUT/dur_small
 echo "durations done"
+for N in 4194304 65536; do bash tools/step_sq.sh $N two ${TAG}x/sq > /dev/null 2>&1; done
+cat $OUT/sq/step_sq_4194304_two.txt $OUT/sq/step_sq_65536_two.txt > $OUT/step_sq.txt 2>/dev/null; echo "sq done"
 timeout -k 10 400 bash tools/step_ledger.sh 4194304 ${TAG}x/ledger > $OUT/ledger.log 2>&1; cp $OUT/ledger/step_ledger.txt $OUT/step_ledger.txt; cp $OUT/ledger/step_ledger.json $OUT/step_ledger.json; echo "ledger done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/upd -- python3 tools/update_prof.py > $OUT/update_prof.txt 2>&1
 find $OUT/upd -name "*kernel_stats.csv" -exec cp {} $OUT/update_kernel_stats.csv \;
