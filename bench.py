@@ -437,6 +437,11 @@ def main():
                     stream["traffic_over_algorithmic"] = led.get("two_kernel_bytes_per_step", 0) / float(ALGO_BYTES_PER_STEP)
                     stream["step_kernel_traffic_over_algorithmic"] = led.get("step_kernel_bytes_per_step", 0) / float(ALGO_BYTES_PER_STEP)
                     stream["step_random_traffic_over_algorithmic"] = (led.get("step_random_bytes_per_step") or 0) / float(ALGO_BYTES_PER_STEP)
+                    if led.get("two_kernel_bytes_per_step_calibrated"):
+                        # FETCH_SIZE doubled for the streamed reads only, not for the scattered record reads of the games that
+                        # end (profiles/<tag>_fetch_calibration.txt); the figures above double it everywhere, as the guide says
+                        stream["traffic_over_algorithmic_calibrated"] = led["two_kernel_bytes_per_step_calibrated"] / float(ALGO_BYTES_PER_STEP)
+                        stream["step_random_traffic_over_algorithmic_calibrated"] = (led.get("step_random_bytes_per_step_calibrated") or 0) / float(ALGO_BYTES_PER_STEP)
                     stream["traffic_provenance"] = led_prov
                 if rank == 0:
                     out["roofline_step_api"]["streaming"] = stream

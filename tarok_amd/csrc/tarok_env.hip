@@ -415,7 +415,8 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     // group g0 + q; they are handed round with v_readlane (a refill wave with nothing to do — most of them, in most
     // launches — costs a launch as much wave-slot time as a step wave: sixteen loads behind sixteen tests were a fifth of it)
     const u32 lane = tid & 63u;
-    const bool mine_has = lane < 4 * TK_REFILL_FAN && (lane >> 2) < fan && g0 + (lane >> 2) < play_groups;
+    const bool mine_has = lane < 4 * TK_REFILL_FAN && (lane >> 2) < fan && g0 + (lane >> 2) < play_groups &&
+                          ((lane & 2u) == 0 || (BULK && bulk_on));     // (the stretch lists' lengths only where they are used)
     const u32 mine = mine_has ? rcount[TK_RC(g0 + (lane >> 2), lane & 3u)] : 0u;
     launch_counted(epoch);
     const u32 phase = (u32)__builtin_amdgcn_readfirstlane((int)launch_phase(count)), par = phase & 1u;   // (a scalar: it selects lanes below)
