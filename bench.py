@@ -327,7 +327,7 @@ def main():
         pmc, prov = load_profile("%s_pmc_fetch_write_%d.json" % (PROFILE_TAG, n), sha)
         traffic = pmc.get("k_play_traffic_bytes_per_launch_cards%d" % cards) if pmc else None
         roof = {"bound": "instruction issue (see issue_roofline); the HBM side is reported here: achieved / peak = hbm_frac" if cards > 1 else "hbm",
-                "kernel": "k_play_wide (tarok_krog_random)" if cards > 1 else "k_step<true> (tarok_step_random)",
+                "kernel": "k_play_wide (tarok_krog_random)" if cards > 1 else "k_step<true, .> (tarok_step_random)",
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "launch_us": k_us, "steps_per_launch": n * plan["lock_steps_per_launch"],
                 "traffic": traffic, "traffic_provenance": prov, "algorithmic": algo}
         if cards > 1 and traffic:
@@ -399,7 +399,7 @@ def main():
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
         if rank == 0:
             ach = ALGO_BYTES_PER_STEP * n / (us0 * 1e-6) / 1e9
-            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false> (tarok_step) behind k_policy_x4 (tarok_policy_random)",
+            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false, true> (tarok_step; at this size the instantiation with the bulk deals) behind k_policy (tarok_policy_random)",
                                         "accounting": "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step" % n,
                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                         "us_per_lock_step": us0, "traffic": None,

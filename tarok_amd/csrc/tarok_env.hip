@@ -411,23 +411,29 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
                                         u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
                                         u32 *__restrict__ rcount, const u64 *__restrict__ elist) {
     u32 g0 = rblock * fan;
-    // all four list lengths of the workgroup's (up to eight) groups with ONE load per wave: lane 4 q + k holds length k of
-    // group g0 + q; they are handed round with v_readlane (a refill wave with nothing to do — most of them, in most
-    // launches — costs a launch as much wave-slot time as a step wave: sixteen loads behind sixteen tests were a fifth of it)
-    const u32 lane = tid & 63u;
-    const bool mine_has = lane < 4 * TK_REFILL_FAN && (lane >> 2) < fan && g0 + (lane >> 2) < play_groups &&
-                          ((lane & 2u) == 0 || (BULK && bulk_on));     // (the stretch lists' lengths only where they are used)
-    const u32 mine = mine_has ? rcount[TK_RC(g0 + (lane >> 2), lane & 3u)] : 0u;
+    // (every thread loads the lengths itself.  One load per wave — lane 4 q + k fetching length k of group g0 + q, handed round
+    // with v_readlane — cut a refill wave's 180 instructions of loads and tests to 30 and FAILED tools/soak_mixed.py within
+    // 1,600 lock-steps at 65,536 games, bulk deals on or off: fresh games with a few stray bits, the marks of a next-game line
+    // read while it was written.  The two forms compute the same numbers; why the second breaks is not understood, so it is
+    // not used: profiles/r03_ab_step.txt (f))
+    u32 len0[TK_REFILL_FAN], len1[TK_REFILL_FAN];
+#pragma unroll
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) {
+        bool has = q < fan && g0 + q < play_groups;
+        len0[q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
+        len1[q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
+    }
     launch_counted(epoch);
-    const u32 phase = (u32)__builtin_amdgcn_readfirstlane((int)launch_phase(count)), par = phase & 1u;   // (a scalar: it selects lanes below)
+    const u32 phase = launch_phase(count), par = phase & 1u;
     if (!BULK) {                 // empty the stretch lists
         if (tid < 2 * fan && g0 + tid / 2 < play_groups) rcount[TK_RC(g0 + tid / 2, 2 + (tid & 1))] = 0u;
     }
     u32 cum[TK_REFILL_FAN + 1];
     cum[0] = 0;
     u32 which = par ^ 1u;
+    const u32 odd = 0u - par;    // (a mask, not a select between the arrays: that becomes a parity-indexed array in scratch)
 #pragma unroll
-    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + (u32)__builtin_amdgcn_readlane((int)mine, (int)(4 * q + which));
+    for (u32 q = 0; q < TK_REFILL_FAN; q++) cum[q + 1] = cum[q] + ((len0[q] & odd) | (len1[q] & ~odd));
     const bool any = cum[TK_REFILL_FAN] != 0;                 // (the same in every thread: nobody writes these lengths in this launch)
     // the lists of the workgroup's groups, one after the other, entry j on thread j mod nthreads; BULK: a second pass (the
     // same code: one copy of the deal) over the stretch lists in the launches that work them off
@@ -441,8 +447,10 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
             which = ((phase / TK_BULK_EVERY) & 1u) ^ 1u;     // the stretch before this one
             lists = elist; cap = TK_BULK_CAP;
 #pragma unroll
-            for (u32 q = 0; q < TK_REFILL_FAN; q++)
-                cum[q + 1] = cum[q] + min((u32)__builtin_amdgcn_readlane((int)mine, (int)(4 * q + 2 + which)), (u32)TK_BULK_CAP);
+            for (u32 q = 0; q < TK_REFILL_FAN; q++) {
+                bool has = q < fan && g0 + q < play_groups;
+                cum[q + 1] = cum[q] + (has ? min(rcount[TK_RC(g0 + q, 2 + which)], (u32)TK_BULK_CAP) : 0u);
+            }
         }
         for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
             u32 q = 0;
@@ -1139,18 +1147,17 @@ __device__ __forceinline__ void step_role(
 }
 
 #define TK_STEP_ARGS                                                                                                              \
-    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan, u32 lazy,                          \
+    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,                                    \
         const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
         ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
         u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ elist
-#ifndef TK_STEP_LAZY
-#define TK_STEP_LAZY true          // (false: diagnostic build, every emptied line on the per-launch lists as in k_play_wide)
-#endif
 #ifndef TK_STEP_WAVES
 #define TK_STEP_WAVES 4            // waves per SIMD the one-card kernel is compiled for (diagnostic builds: 5, 6, 8)
 #endif
-template <bool RANDOM>
+// LAZY: the env deals the lines its one-card launches empty in bulk (TAROK_OPT_LAZY_REFILL, refill_role<true>); the other
+// instantiation carries none of that — where the batch streams, a dozen instructions per step wave are 3 % of a launch
+template <bool RANDOM, bool LAZY>
 __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STEP_WAVES))) void k_step(TK_STEP_ARGS) {
     u32 count = launch_count(epoch);
     // The refill workgroups are spread among the play workgroups — block q (fan + 1) works the lists of the `fan`
@@ -1160,9 +1167,9 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STE
     __shared__ u32 finq[FINQ_WORDS][TK_BLOCK];
     u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
     if (r == 0)
-        refill_role<TK_STEP_LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, lazy != 0, aux, rlist, rcount, elist);
+        refill_role<LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, LAZY, aux, rlist, rcount, elist);
     else
-        step_role<RANDOM, TK_STEP_LAZY>(blockIdx.x - q - 1, threadIdx.x, true, 255u, lazy != 0, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
+        step_role<RANDOM, LAZY>(blockIdx.x - q - 1, threadIdx.x, true, 255u, LAZY, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
                                 reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
 }
 
@@ -2369,11 +2376,12 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     if (cards == 1) {
-#define TK_LAUNCH_STEP(R)                                                                                                \
-    hipLaunchKernelGGL((k_step<R>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
-                       fan, e->lazy_refill, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
+#define TK_LAUNCH_STEP(R, Z)                                                                                             \
+    hipLaunchKernelGGL((k_step<R, Z>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
+                       fan, action_in, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01, e->s23, e->aux, e->cnt,  \
                        e->gkey, e->rlist, e->rcount, e->elist)
-        if (random) TK_LAUNCH_STEP(true); else TK_LAUNCH_STEP(false);
+        if (e->lazy_refill) { if (random) TK_LAUNCH_STEP(true, true); else TK_LAUNCH_STEP(false, true); }
+        else                { if (random) TK_LAUNCH_STEP(true, false); else TK_LAUNCH_STEP(false, false); }
 #undef TK_LAUNCH_STEP
         return;
     }

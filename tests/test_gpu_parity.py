@@ -1027,6 +1027,40 @@ def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S, lazy):
     env.close()
 
 
+@pytest.mark.parametrize("lazy", [None, 0])
+def test_launch_kinds_mixed_at_full_size_vs_oracle(T, O, S, lazy):
+    """65,536 games, forty segments of a seeded mix — graph-replayed and eager one-card launches, the two-kernel path,
+    multi-card launches of 4 .. 128 cards between them (with the one-card step's bulk deals those drop the stretch
+    lists, and slots come back to stale lines) — 1,867 lock-steps without a host synchronisation in between: every
+    slot's episode number, score sums, canonical state and observation word vs the oracle.  (A refill role that
+    fetched its list lengths with one load per wave passed every other test of this file and failed this sequence at
+    lock-step 1,604: tools/soak_mixed.py is the longer version.)"""
+    n, seed = 65536, 11
+    rnd = np.random.RandomState(1)
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
+    env.reset()
+    steps = 0
+    for seg in range(40):
+        kind = rnd.choice(["random", "two", "eager", "krog"])
+        if kind == "random":
+            k = int(rnd.choice([16, 48, 80, 112])); env.run_random(k, cards_per_launch=1, graph_chunk=16, auto_reset=True)
+        elif kind == "two":
+            k = int(rnd.choice([20, 60, 100])); env.run_random(k, cards_per_launch=0, graph_chunk=20, auto_reset=True)
+        elif kind == "eager":
+            k = int(rnd.randint(1, 23))
+            for _ in range(k):
+                env.step_random(auto_reset=True)
+        else:
+            k = int(rnd.choice([4, 8, 28, 48, 128])); env.krog_random(k, auto_reset=True)
+        steps += k
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
+    ep, ss = env.counters()
+    assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
+    assert (env.state() == ref["lanes"]).all()
+    assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all()
+    env.close()
+
+
 def test_config1_single_klop_game_through_the_main_equivalent(T, O, S):
     """BASELINE config 1: ONE 4-player Klop game (the reference supports 4 players only,
     SURVEY §0) driven through the build's main-equivalent with reference-shaped players;

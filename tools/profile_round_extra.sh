@@ -29,4 +29,5 @@ python3 tools/update_prof.py 2>&1 | grep -v amdgpu.ids > $OUT/update_times.txt
 python3 tools/chain_stamps.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_stamps.txt; echo "learner done"
 timeout -k 10 500 python3 tools/soak_parity.py > $OUT/soak_parity.txt 2>&1; echo "soak rc $?"
 timeout -k 10 300 python3 tools/soak_paths.py >> $OUT/soak_parity.txt 2>&1; echo "paths rc $?"
+timeout -k 10 400 python3 tools/soak_mixed.py 2>&1 | grep -v amdgpu.ids >> $OUT/soak_parity.txt; echo "mixed rc $?"
 echo ALL DONE
