@@ -18,6 +18,8 @@ def oracle(seed, n, steps, parts=64):
             "lanes": np.concatenate([r["lanes"] for r in res], axis=1), "obs": np.concatenate([r["obs"] for r in res])}
 
 CONFIGS = ((65536, 6000, None), (65536, 3000, 0), (1 << 20, 1200, None), (1 << 20, 1200, 1))
+if os.environ.get("SOAK_MORE"):                  # (other sizes — fan 4 — and other segment sequences)
+    CONFIGS = ((1 << 18, 4000, None), (1 << 19, 2500, None), (1 << 18, 2500, 0), (65536, 6001, None), (65536, 6002, None), (65536, 6003, 0))
 if os.environ.get("SOAK_DEFAULT_ONLY"):          # (libraries without TAROK_OPT_LAZY_REFILL: tools/ab/*.so)
     CONFIGS = tuple(c for c in CONFIGS if c[2] is None)
 for n, target, lazy in CONFIGS:
