@@ -366,8 +366,8 @@ __device__ __forceinline__ u32 launch_phase(u32 count) {
     return q;
 }
 __device__ __forceinline__ u32 launch_parity(u32 count) { return launch_phase(count) & 1u; }
-// call after launch_count in program order — one lane's read and add of one address stay in that order — and before the
-// first use of its value: the add counts as an outstanding memory operation of the wave, and issued only once the
+// call after launch_count in program order — one lane's read and add of one address stay in that order — behind a barrier
+// that every wave of the workgroup passes after ITS read of the count (refill_role), and before the first use of its value: the add counts as an outstanding memory operation of the wave, and issued only once the
 // count has arrived it adds a memory-side round trip to the life of every step wave (+4 us per launch at 4 M games)
 __device__ __forceinline__ void launch_counted(u32 *epoch) {
     if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), TK_PHASES * launch_shard_size() - 1u);
@@ -411,11 +411,10 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
                                         u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
                                         u32 *__restrict__ rcount, const u64 *__restrict__ elist) {
     u32 g0 = rblock * fan;
-    // (every thread loads the lengths itself.  One load per wave — lane 4 q + k fetching length k of group g0 + q, handed round
-    // with v_readlane — cut a refill wave's 180 instructions of loads and tests to 30 and FAILED tools/soak_mixed.py within
-    // 1,600 lock-steps at 65,536 games, bulk deals on or off: fresh games with a few stray bits, the marks of a next-game line
-    // read while it was written.  The two forms compute the same numbers; why the second breaks is not understood, so it is
-    // not used: profiles/r03_ab_step.txt (f))
+    // (every thread loads the two per-launch lengths of every group itself, the stretch lists' lengths only in the pass that
+    // works them off.  Forms that fetched all four lengths at the top of the role — one load per wave handed round with
+    // v_readlane, or every thread for itself — and kept them in scalar registers were up to 150 instructions shorter and
+    // FAILED tools/soak_mixed.py within 1,600 lock-steps at 65,536 games; why is not understood: profiles/r03_ab_step.txt (f))
     u32 len0[TK_REFILL_FAN], len1[TK_REFILL_FAN];
 #pragma unroll
     for (u32 q = 0; q < TK_REFILL_FAN; q++) {
@@ -423,6 +422,11 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
         len0[q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
         len1[q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
     }
+    // The workgroup's add must not overtake the count reads of its OWN later waves (every thread reads the count at the top
+    // of the kernel; were this the last workgroup of its counter to add, a wave that read after the add would see the next
+    // launch's band: the wrong parity, the list the running launch is writing).  The barrier puts every wave's read into the
+    // memory pipe ahead of the add; step_role and play_role add behind their first barrier as well.
+    __syncthreads();
     launch_counted(epoch);
     const u32 phase = launch_phase(count), par = phase & 1u;
     if (!BULK) {                 // empty the stretch lists
