@@ -12,6 +12,8 @@ from tarok_amd import TarokVecEnv, karte as K
 from oracle import oracle as O
 
 def oracle(seed, n, steps, parts=64):
+    if n % parts:
+        return O.run_autoreset(seed, 0, n, K.MIX_ALL, steps, threads=16)
     with ThreadPoolExecutor(16) as ex:
         res = list(ex.map(lambda k: O.run_autoreset(seed, k * (n // parts), n // parts, K.MIX_ALL, steps), range(parts)))
     return {"episode": np.concatenate([r["episode"] for r in res]), "score_sum": np.concatenate([r["score_sum"] for r in res]),
@@ -22,6 +24,8 @@ if os.environ.get("SOAK_MORE"):                  # (other sizes — fan 4 — an
     CONFIGS = ((1 << 18, 4000, None), (1 << 19, 2500, None), (1 << 18, 2500, 0), (65536, 6001, None), (65536, 6002, None), (65536, 6003, 0))
 if os.environ.get("SOAK_DEFAULT_ONLY"):          # (libraries without TAROK_OPT_LAZY_REFILL: tools/ab/*.so)
     CONFIGS = tuple(c for c in CONFIGS if c[2] is None)
+if os.environ.get("SOAK_MORE2"):                 # (longer runs, other sequences again)
+    CONFIGS = ((65536, 12007, None), (65536, 12011, 0), (1 << 20, 2503, None), (1 << 20, 2509, 1), (1 << 17, 9001, None), (20000, 9007, None))
 for n, target, lazy in CONFIGS:
     rnd = np.random.RandomState(n % 1000 + target)
     env = TarokVecEnv(n, seed=11, mix=K.MIX_ALL, lazy_refill=lazy)
