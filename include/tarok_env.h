@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TAROK_ABI_VERSION 4
+#define TAROK_ABI_VERSION 5
 #define TAROK_MAX_CARDS_PER_LAUNCH 192 /* tarok_krog_random / tarok_run_random: cards of every game per launch */
 #define TAROK_GAMES_AHEAD 14           /* games every slot keeps dealt ahead for TAROK_AUTO_RESET (tarok_prefetch)  */
 
@@ -97,10 +97,16 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
 void tarok_destroy(tarok_env *env);
 int64_t tarok_num_games(const tarok_env *env);
 
-/* Launch tuning of an env; the results never depend on it.  Defaults from the batch size at tarok_create.
- *   TAROK_OPT_REFILL_FAN   1..8 play workgroups whose refill lists one refill workgroup works off
+/* Launch tuning of an env; the results never depend on it, at whatever point of a run it is changed.  Defaults from the
+ * batch size at tarok_create.
+ *   TAROK_OPT_REFILL_FAN   1..8 play workgroups whose refill lists one refill workgroup works off.  It sets the step
+ *                               launches' grid: changing it after the env's first step launch synchronises the DEVICE,
+ *                               restarts the env's launch counters and empties its refill lists (lines whose deal is
+ *                               dropped are dealt by their slots when they get there) — do it between phases, not per step,
+ *                               and not while a caller's graph holding this env's step launches is to be replayed
  *   TAROK_OPT_LAZY_REFILL  0/1  tarok_step / tarok_step_random: the next-game lines their slots empty are dealt in bulk
- *                               every sixteenth launch instead of in the launch after (default: on below 2^20 games) */
+ *                               every sixteenth launch instead of in the launch after (default: on below 2^20 games);
+ *                               free to change between any two launches */
 #define TAROK_OPT_REFILL_FAN 2
 #define TAROK_OPT_LAZY_REFILL 3
 int tarok_set_option(tarok_env *env, int option, int value);
@@ -401,6 +407,18 @@ int tarok_learn_adam(tarok_env *env, float *param, const float *grad, float *m, 
 /* Diagnostics: when `stamps` (device, [ceil(N/64), 3] u64) is non-NULL every wave of the step
  * kernels records {s_memrealtime at entry, at exit, shader cycles in between}.  NULL turns it off. */
 int tarok_debug_stamps(tarok_env *env, uint64_t *stamps);
+/* The same with the buffer's capacity in 64-bit words stated: a kernel writes its stamps only into a buffer that
+ * holds all of them — the step kernels 3 per wave (3 * ceil(N/64)), tarok_policy_mlp and tarok_learn_chain 8 per
+ * workgroup (8 * ceil(N/128), 8 * ceil(B/96)).  tarok_debug_stamps registers the step kernels' size. */
+int tarok_debug_stamps_sized(tarok_env *env, uint64_t *stamps, int64_t n_words);
+/* Self-test of the refill role as the step kernels compile it (tests only; it takes over the env's refill lists and
+ * next-game lines and leaves them empty: tarok_reset before the env is used again).  Every group's lists are filled by
+ * hand — every slot, episodes episode0+1 .. episode0+per_slot (1..14), in list order `order` (0 ascending slots, 1
+ * descending, 2 scattered) — `reps` step launches of `kind` (0 tarok_step_random, 1 tarok_policy_random + tarok_step,
+ * 2 tarok_krog_random of 4 cards, 3 of 2 cards) work them off, and every line is compared with a re-deal by a kernel
+ * of its own.  report_out (host, 49 u64): [0] lines that differ, then {slot, episode, play word read / expected, seat
+ * word read / expected} of the first eight. */
+int tarok_debug_refill_selftest(tarok_env *env, int kind, int per_slot, uint32_t episode0, int order, int reps, uint64_t *report_out);
 
 /* Canonical state for parity checks / checkpoints: lanes_out [10,N] u64. */
 int tarok_get_state(tarok_env *env, uint64_t *lanes_out, void *stream);

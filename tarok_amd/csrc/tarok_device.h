@@ -30,6 +30,25 @@
 typedef unsigned long long u64;
 typedef uint32_t u32;
 
+// gfx950 ERRATUM GUARD (DESIGN.md §3 "the refill-role bug", tarok_amd/isa_check.py, profiles/r04_refill_root_cause.txt).
+// v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 shift by v0 instead of by their amount register when that register is the
+// LAST VGPR the wave was allocated (gfx90a's "Shift64HighRegBug"; ROCm 7.2.0's compiler works round it on gfx90a only).
+// Every kernel of this library is declared TK_KERNEL(threads, B) — it may use v0 .. v(B-2) only — and starts with
+// TK_VGPR_TOP(B, B-1), which marks v(B-1) used: the wave's allocation is always exactly B registers (B a multiple of the
+// allocation granule, 8) and no value ever lives in the last one.  B is the kernel's occupancy bucket (<= 64: 8 waves per
+// SIMD, 80: 6, 96: 5, 128: 4, 168: 3, 256: 2), so the guard costs one register of the bucket and no occupancy.  (A kernel
+// that needs more than 256 registers — k_learn_dw — holds the rest in accumulation registers, which follow the VGPRs in the
+// unified file: the row behind its last VGPR is always allocated.)
+#define TK_VGPR_BUDGET(B) __attribute__((amdgpu_num_vgpr((B) - 1)))
+#define TK_KERNEL(threads, B) __global__ __launch_bounds__(threads) TK_VGPR_BUDGET(B)
+#define TK_VGPR_STR2(x) #x
+#define TK_VGPR_STR(x) TK_VGPR_STR2(x)
+#define TK_VGPR_TOP(B, TOP)                                                                                           \
+    do {                                                                                                              \
+        static_assert((B) % 8 == 0 && (B) <= 256 && (TOP) == (B) - 1, "TK_VGPR_TOP(B, B - 1), B a multiple of 8");     \
+        asm volatile("" ::: "v" TK_VGPR_STR(TOP));                                                                    \
+    } while (0)
+
 #define TK_BIT(i) (1ULL << (i))
 #define TK_DECK ((1ULL << 54) - 1)
 #define TK_TAROK (((1ULL << 22) - 1) << 32)

@@ -40,6 +40,7 @@
 #define TK_BLOCK 256               // (512 / 1024: diagnostics builds only, tools/ab_build.sh — more play waves per SIMD on fewer CUs)
 #endif
 #define TK_PF_SLOTS (4 * TK_BLOCK)
+#define TK_GRAPH_CACHE 16          // instantiated graphs kept per env (tarok_run_random)
 #define TK_REFILL_CAP (TK_BLOCK * TK_AHEAD) // refill-list entries per play workgroup and launch (<= TK_AHEAD per slot)
 #define TK_REFILL_FAN 8            // play workgroups whose lists one refill workgroup works off
 // list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
@@ -116,12 +117,21 @@ struct tarok_env {
     uint32_t lazy_refill;    // the one-card step lists emptied lines for a bulk deal every TK_BULK_EVERY launches (refill_role)
     int n_cus;               // compute units of the device (k_learn_dw's grid), 0 = not asked yet
     float *adam_sumsq;       // k_learn_gnorm's partial sums
-    u64 *stamps;             // diagnostics only
-    hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graph
-    // cached graph
-    hipGraphExec_t gexec;
-    int g_fused, g_chunk, g_flags, g_prefetch;
-    void *g_action, *g_reward, *g_done, *g_obs;
+    u64 *stamps;             // diagnostics only (tarok_debug_stamps)
+    size_t stamps_words;     // its capacity: a kernel that would write more gets no stamps pointer
+    int launched;            // a step launch has been issued (tarok_set_option: a change of the grid must restart the launch counters)
+    hipStream_t cap_stream;  // capture-only stream for tarok_run_random's graphs
+    // tarok_run_random's instantiated graphs.  An exec is NEVER destroyed while launches of it may still be queued (round 3
+    // destroyed the one cached exec whenever the segment kind changed, with up to a hundred of its launches in flight):
+    // every (launch kind, chunk, flags, buffers, launch tuning) keeps its exec until tarok_destroy, which synchronises the
+    // device first; a full cache is emptied behind a device synchronisation.
+    struct GraphEntry {
+        hipGraphExec_t exec;
+        int fused, chunk, flags, prefetch;
+        void *action, *reward, *done, *obs, *stamps;
+        uint32_t fan, lazy;
+    } graphs[TK_GRAPH_CACHE];
+    int n_graphs;
 };
 
 static thread_local int g_last_hip = 0;
@@ -155,12 +165,13 @@ __device__ __forceinline__ void store_game(const Game &g, ulonglong2 *s01, ulong
 }
 
 // Igra.razdeli + engine construction + talon exchange for every slot.
-__global__ __launch_bounds__(TK_BLOCK) void k_reset(
+TK_KERNEL(TK_BLOCK, 80) void k_reset(
     int64_t n, u64 seed, u64 offset, u32 episode, int mix, int flags,
     const uint8_t *__restrict__ deals, const int8_t *__restrict__ contract, const int8_t *__restrict__ declarer,
     const int8_t *__restrict__ king, const int8_t *__restrict__ choice, const uint8_t *__restrict__ discards,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
     uint16_t *__restrict__ nstale, u64 *__restrict__ gkey) {
+    TK_VGPR_TOP(80, 79);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 key = game_key(seed, offset + (u64)i, episode);
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_reset(
 }
 
 // Deal game `episode` of slot j ahead of time into its line (episode mod TK_AHEAD).
-__device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t j, u32 episode, u64 seed, u64 offset, int mix) {
+__device__ __forceinline__ void deal_into_buffer(Aux *aux, int64_t j, u32 episode, u64 seed, u64 offset, int mix) {
     u64 key = game_key(seed, offset + (u64)j, (u64)episode);
     u64 h0, h1, h2, h3, tal;
     deal_thread(key, h0, h1, h2, h3, tal);
@@ -229,9 +240,10 @@ __device__ __forceinline__ void deal_into_buffer(Aux *__restrict__ aux, int64_t 
 // nstale: bit k = episode+1+k missing).  Each workgroup compacts the missing lines of its
 // 1024-slot tile into an LDS list (4 flag bytes per thread) and deals list entry j on thread j,
 // so the sorting network runs on dense lanes.
-__global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
-                                                      Aux *__restrict__ aux, const Counters *__restrict__ cnt,
+TK_KERNEL(TK_BLOCK, 128) void k_prefetch(int64_t n, u64 seed, u64 offset, int mix,
+                                                      Aux *aux, const Counters *__restrict__ cnt,
                                                       uint16_t *__restrict__ nstale) {
+    TK_VGPR_TOP(128, 127);
     __shared__ unsigned short list[TK_AHEAD * TK_PF_SLOTS];
     __shared__ u32 count;
     int64_t base = (int64_t)blockIdx.x * TK_PF_SLOTS;
@@ -260,10 +272,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_prefetch(int64_t n, u64 seed, u64 
     }
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_exchange(int64_t n, const int8_t *__restrict__ choice,
+TK_KERNEL(TK_BLOCK, 64) void k_exchange(int64_t n, const int8_t *__restrict__ choice,
                                                       const uint8_t *__restrict__ discards,
                                                       ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23,
                                                       const u64 *__restrict__ gkey) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     Game g;
@@ -278,9 +291,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_exchange(int64_t n, const int8_t *
     store_game(g, s01, s23, i);
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_legal(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(TK_BLOCK, 64) void k_legal(int64_t n, const ulonglong2 *__restrict__ s01,
                                                    const ulonglong2 *__restrict__ s23, u64 *__restrict__ obs,
                                                    int8_t *__restrict__ seat) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     Game g;
@@ -289,8 +303,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_legal(int64_t n, const ulonglong2 
     if (seat) seat[i] = (int8_t)((g.leader + g.nt) & 3);
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__restrict__ obs,
+TK_KERNEL(TK_BLOCK, 64) void k_policy(int64_t n, const u64 *__restrict__ obs,
                                                     const u64 *__restrict__ gkey, uint8_t *__restrict__ action) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 o = obs[i];
@@ -305,8 +320,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_policy(int64_t n, const u64 *__res
 // (16.3 us for 71 MB, profiles/r03_step_durations.txt; this form 13.0 us).  A workgroup takes 1,024 consecutive games; thread t the
 // pairs (2t, 2t+1) of its first and of its second half, so that every load is a contiguous 16 bytes per lane and
 // every store two bytes per lane of one 128-byte line per wave.
-__global__ __launch_bounds__(TK_BLOCK) void k_policy_x4(int64_t n, const u64 *__restrict__ obs,
+TK_KERNEL(TK_BLOCK, 64) void k_policy_x4(int64_t n, const u64 *__restrict__ obs,
                                                        const u64 *__restrict__ gkey, uint8_t *__restrict__ action) {
+    TK_VGPR_TOP(64, 63);
     int64_t base = (int64_t)blockIdx.x * (4 * TK_BLOCK);
     if (base + 4 * TK_BLOCK <= n) {
         int64_t p0 = base + 2 * threadIdx.x, p1 = p0 + 2 * TK_BLOCK;
@@ -373,6 +389,19 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {
     if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), TK_PHASES * launch_shard_size() - 1u);
 }
 
+// WHAT WORKGROUPS HAND EACH OTHER, AND THROUGH WHICH CACHE (DESIGN.md §3 has the table).  Five buffers are written by one
+// workgroup and read by another: the next-game lines (`aux`: refill role -> play / step role), the per-launch refill lists
+// and their lengths (`rlist`, `rcount[0..1]`: play / step role -> refill role), the stretch lists and their lengths (`elist`,
+// `rcount[2..3]`: step role -> refill role and, the lengths, back to the step role of a LATER launch) and the launch counters
+// (`epoch`).  Except for `epoch` every such word is read in a LATER launch than it was written: the kernel boundary (release at
+// the end of a launch, acquire at the start of the next: L2 write-back and invalidate across the XCDs, vector L1 and scalar
+// cache invalidated) is the only ordering the protocol relies on, and within a launch no workgroup reads a word another one
+// writes in that launch.  The code says so: none of these pointers is `__restrict__` or `const` (nothing licenses the
+// compiler to keep such a word in the scalar cache or to merge its reads across a barrier), every length and list entry is
+// read with an agent-scope atomic load (tk_ld: a vector load that misses the L1), and `epoch` — the one buffer read and
+// written within a launch — only with agent-scope atomics.
+template <class T> __device__ __forceinline__ T tk_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // The step kernels.  One launch plays `cards` cards of every game:
 //   k_step (step_role), cards = 1: tarok_step — the card comes from `action_in` (an external policy) — and
 //                   tarok_step_random (the Bot policy, Igralec.py:158-159, evaluated in-kernel);
@@ -408,19 +437,19 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {
 // to them, deals that game in place and lists all fourteen.
 template <bool BULK>
 __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
-                                        u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *__restrict__ aux, const u64 *__restrict__ rlist,
-                                        u32 *__restrict__ rcount, const u64 *__restrict__ elist) {
+                                        u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *aux, u64 *rlist, u32 *rcount, u64 *elist) {
     u32 g0 = rblock * fan;
-    // (every thread loads the two per-launch lengths of every group itself, the stretch lists' lengths only in the pass that
-    // works them off.  Forms that fetched all four lengths at the top of the role — one load per wave handed round with
-    // v_readlane, or every thread for itself — and kept them in scalar registers were up to 150 instructions shorter and
-    // FAILED tools/soak_mixed.py within 1,600 lock-steps at 65,536 games; why is not understood: profiles/r03_ab_step.txt (f))
+    // every thread loads the two per-launch lengths of every group itself, the stretch lists' lengths only in the pass that
+    // works them off.  (Round 3 shipped this form because shorter ones — all four lengths with one load per wave, sums in
+    // scalar registers — "failed for reasons not understood".  The reason is understood now and had nothing to do with the
+    // lengths: those builds had 104 VGPRs with a shift amount of the deal in v103, and gfx950 mis-executes a 64-bit shift
+    // whose amount sits in the last allocated VGPR — TK_VGPR_TOP, tarok_device.h; profiles/r04_refill_root_cause.txt.)
     u32 len0[TK_REFILL_FAN], len1[TK_REFILL_FAN];
 #pragma unroll
     for (u32 q = 0; q < TK_REFILL_FAN; q++) {
         bool has = q < fan && g0 + q < play_groups;
-        len0[q] = has ? rcount[TK_RC(g0 + q, 0)] : 0u;
-        len1[q] = has ? rcount[TK_RC(g0 + q, 1)] : 0u;
+        len0[q] = has ? tk_ld(&rcount[TK_RC(g0 + q, 0)]) : 0u;
+        len1[q] = has ? tk_ld(&rcount[TK_RC(g0 + q, 1)]) : 0u;
     }
     // The workgroup's add must not overtake the count reads of its OWN later waves (every thread reads the count at the top
     // of the kernel; were this the last workgroup of its counter to add, a wave that read after the add would see the next
@@ -441,7 +470,7 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     const bool any = cum[TK_REFILL_FAN] != 0;                 // (the same in every thread: nobody writes these lengths in this launch)
     // the lists of the workgroup's groups, one after the other, entry j on thread j mod nthreads; BULK: a second pass (the
     // same code: one copy of the deal) over the stretch lists in the launches that work them off
-    const u64 *lists = rlist;
+    u64 *lists = rlist;
     u32 cap = TK_REFILL_CAP;
     const bool bulk = BULK && bulk_on && phase % TK_BULK_EVERY == 0;      // (bulk_on: the env's step workgroups fill stretch lists)
 #pragma nounroll
@@ -453,7 +482,7 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
 #pragma unroll
             for (u32 q = 0; q < TK_REFILL_FAN; q++) {
                 bool has = q < fan && g0 + q < play_groups;
-                cum[q + 1] = cum[q] + (has ? min(rcount[TK_RC(g0 + q, 2 + which)], (u32)TK_BULK_CAP) : 0u);
+                cum[q + 1] = cum[q] + (has ? min(tk_ld(&rcount[TK_RC(g0 + q, 2 + which)]), (u32)TK_BULK_CAP) : 0u);
             }
         }
         for (u32 j = tid; j < cum[TK_REFILL_FAN]; j += nthreads) {
@@ -463,7 +492,7 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
             u32 base = 0;
 #pragma unroll
             for (u32 r = 0; r < TK_REFILL_FAN; r++) base = (r == q) ? cum[r] : base;
-            u64 en = lists[((int64_t)(g0 + q) * 2 + which) * cap + (j - base)];
+            u64 en = tk_ld(&lists[((int64_t)(g0 + q) * 2 + which) * cap + (j - base)]);
             deal_into_buffer(aux, (int64_t)(g0 + q) * TK_BLOCK + (u32)(en & 0xFFFF), (u32)(en >> 32), seed, offset, mix);
         }
     }
@@ -486,8 +515,8 @@ __device__ __forceinline__ void play_role(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 count, u32 *epoch,
     uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *rlist, u32 *rcount, u64 *__restrict__ stamps) {
     __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
     __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
     __shared__ u32 push_count;
@@ -920,10 +949,11 @@ __device__ __forceinline__ void play_role(
     int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 play_groups, u32 *epoch, u32 fan,         \
         uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                                                           \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
-        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
-        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ stamps
+        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,                         \
+        u64 *__restrict__ gkey, u64 *rlist, u32 *rcount, u64 *__restrict__ stamps
 template <bool HIST>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
+TK_KERNEL(TK_BLOCK, 168) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
+    TK_VGPR_TOP(168, 167);
     u32 count = launch_count(epoch);
     if (blockIdx.x >= play_groups)
         refill_role<false>(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
@@ -993,8 +1023,8 @@ __device__ __forceinline__ void step_role(
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 count, u32 *epoch,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ elist,
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *rlist, u32 *rcount, u64 *elist,
     u32 (*__restrict__ finq)[TK_BLOCK] /* LDS [FINQ_WORDS][TK_BLOCK] */) {
     __shared__ unsigned short push_list[TK_REFILL_CAP];   // (how far ahead) * TK_BLOCK + slot in group
     __shared__ u32 push_ep[TK_BLOCK];                     // the slot's episode number at the end of the launch
@@ -1005,7 +1035,7 @@ __device__ __forceinline__ void step_role(
     // (lazy) how full the two stretch lists of this group are: asked for now by every thread (one address per workgroup),
     // looked at when the launch's entries go out — no broadcast, no barrier of its own
     u32 efill0 = 0, efill1 = 0;
-    if (lazy) { efill0 = rcount[TK_RC(group, 2)]; efill1 = rcount[TK_RC(group, 3)]; }
+    if (lazy) { efill0 = tk_ld(&rcount[TK_RC(group, 2)]); efill1 = tk_ld(&rcount[TK_RC(group, 3)]); }
     __syncthreads();
     int64_t i = (int64_t)group * TK_BLOCK + tid;
     bool valid = active && i < n;
@@ -1154,15 +1184,29 @@ __device__ __forceinline__ void step_role(
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,                                    \
         const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
         uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,              \
-        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,            \
-        u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount, u64 *__restrict__ elist
+        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,                         \
+        u64 *__restrict__ gkey, u64 *rlist, u32 *rcount, u64 *elist
 #ifndef TK_STEP_WAVES
 #define TK_STEP_WAVES 4            // waves per SIMD the one-card kernel is compiled for (diagnostic builds: 5, 6, 8)
+#endif
+#if TK_STEP_WAVES == 4             // (the kernel's VGPR bucket and its last register: TK_KERNEL / TK_VGPR_TOP, tarok_device.h)
+#define TK_STEP_VGPRS 128
+#define TK_STEP_VTOP 127
+#elif TK_STEP_WAVES == 5
+#define TK_STEP_VGPRS 96
+#define TK_STEP_VTOP 95
+#elif TK_STEP_WAVES == 6
+#define TK_STEP_VGPRS 80
+#define TK_STEP_VTOP 79
+#else
+#define TK_STEP_VGPRS 64
+#define TK_STEP_VTOP 63
 #endif
 // LAZY: the env deals the lines its one-card launches empty in bulk (TAROK_OPT_LAZY_REFILL, refill_role<true>); the other
 // instantiation carries none of that — where the batch streams, a dozen instructions per step wave are 3 % of a launch
 template <bool RANDOM, bool LAZY>
-__global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STEP_WAVES))) void k_step(TK_STEP_ARGS) {
+TK_KERNEL(TK_BLOCK, TK_STEP_VGPRS) __attribute__((amdgpu_waves_per_eu(TK_STEP_WAVES))) void k_step(TK_STEP_ARGS) {
+    TK_VGPR_TOP(TK_STEP_VGPRS, TK_STEP_VTOP);
     u32 count = launch_count(epoch);
     // The refill workgroups are spread among the play workgroups — block q (fan + 1) works the lists of the `fan`
     // play groups in the blocks after it off — so that their deals (instruction bound, ~2.7k per game) run UNDER the
@@ -1178,10 +1222,11 @@ __global__ __launch_bounds__(TK_BLOCK) __attribute__((amdgpu_waves_per_eu(TK_STE
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
-__global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 offset, u32 episode, int mix,
+TK_KERNEL(TK_BLOCK, 96) void k_rollout(int64_t n, u64 seed, u64 offset, u32 episode, int mix,
                                                      int16_t *__restrict__ scores_out, int16_t *__restrict__ nsteps_out,
                                                      int8_t *__restrict__ seats, u64 *__restrict__ masks,
                                                      uint8_t *__restrict__ actions) {
+    TK_VGPR_TOP(96, 95);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 key = game_key(seed, offset + (u64)i, episode);
@@ -1237,8 +1282,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_rollout(int64_t n, u64 seed, u64 o
 // Each thread builds the four 64-bit words of its own game; then the wave writes one game per
 // iteration: lane L expands bits 4L..4L+3 into 4 bf16 and the 64 lanes store one contiguous
 // 512-byte row (v_readlane broadcasts the words), so the 33 MB/step of features leave as full lines.
-__global__ __launch_bounds__(TK_BLOCK) void k_observe(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(TK_BLOCK, 64) void k_observe(int64_t n, const ulonglong2 *__restrict__ s01,
                                                      const ulonglong2 *__restrict__ s23, uint2 *__restrict__ out) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     bool valid = i < n;
     Game g;
@@ -1329,9 +1375,10 @@ __device__ __forceinline__ u32 ref_type(u32 c) {    // Nevronski_igralec.tip_igr
 }
 
 #define OR_GAMES 64                 // games per workgroup: phase 1 on one wave, phase 2 on all four (16 games each)
-__global__ __launch_bounds__(256) void k_observe_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(256, 64) void k_observe_ref(int64_t n, const ulonglong2 *__restrict__ s01,
                                                    const ulonglong2 *__restrict__ s23, const uint8_t *__restrict__ hist,
                                                    uint4 *__restrict__ rec, int4 *__restrict__ meta) {
+    TK_VGPR_TOP(64, 63);
     __shared__ RefDesc desc[OR_GAMES];
     __shared__ uint8_t hist_s[OR_GAMES][48];
     __shared__ uint8_t rowpos_s[4][64];
@@ -1500,8 +1547,9 @@ __device__ __forceinline__ void write_bit_records(const u64 (*words)[NW], int64_
 // menjaj_talon_v_vektor (Igralec.py:535-543), the input of the exchange decision, for the games that
 // wait for tarok_exchange: [roka 54 | talon (54,6) flattened card-major | igra one-hot 15 | pad 7]
 // = 400 bytes of 0/1; zeros for games in any other phase.
-__global__ __launch_bounds__(TK_BLOCK) void k_observe_exchange_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(TK_BLOCK, 64) void k_observe_exchange_ref(int64_t n, const ulonglong2 *__restrict__ s01,
                                                                   const ulonglong2 *__restrict__ s23, uint2 *__restrict__ out) {
+    TK_VGPR_TOP(64, 63);
     __shared__ u64 words[TK_BLOCK][7];
     int64_t base = (int64_t)blockIdx.x * TK_BLOCK, i = base + threadIdx.x;
     Game g;
@@ -1524,8 +1572,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe_exchange_ref(int64_t n, co
 
 // The bidding input (pripavi_licitiram, Igralec.py:278-281): every seat's hand as 54 bytes of 0/1,
 // [N][4][54].
-__global__ __launch_bounds__(TK_BLOCK) void k_observe_hands_ref(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(TK_BLOCK, 64) void k_observe_hands_ref(int64_t n, const ulonglong2 *__restrict__ s01,
                                                                const ulonglong2 *__restrict__ s23, uint2 *__restrict__ out) {
+    TK_VGPR_TOP(64, 63);
     __shared__ u64 words[TK_BLOCK][4];
     int64_t base = (int64_t)blockIdx.x * TK_BLOCK, i = base + threadIdx.x;
     Game g;
@@ -1547,9 +1596,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_observe_hands_ref(int64_t n, const
 // (bit-expand mask, masked_fill, log_softmax, multinomial, gather) with one pass over 8 MB.
 __device__ __forceinline__ float bf16_to_f32(u32 h) { return __uint_as_float(h << 16); }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__restrict__ logits /* [N,64] bf16 */,
+TK_KERNEL(TK_BLOCK, 256) void k_sample(int64_t n, const uint4 *__restrict__ logits /* [N,64] bf16 */,
                                                     const u64 *__restrict__ obs, const u64 *__restrict__ gkey,
                                                     uint8_t *__restrict__ action, float *__restrict__ logp) {
+    TK_VGPR_TOP(256, 255);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 o = obs[i];
@@ -1605,8 +1655,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_sample(int64_t n, const uint4 *__r
 // of sample index[j] (or of sample j when index is NULL).  One 16-byte chunk (one byte of a
 // feature word -> 8 bf16) per thread, 32 threads per sample: the gather and the expansion in one
 // pass, full 512-byte rows written per 32 lanes.
-__global__ __launch_bounds__(TK_BLOCK) void k_expand_features(int64_t n, const u64 *__restrict__ words /* [.,4] */,
+TK_KERNEL(TK_BLOCK, 64) void k_expand_features(int64_t n, const u64 *__restrict__ words /* [.,4] */,
                                                              const int64_t *__restrict__ index, uint4 *__restrict__ out) {
+    TK_VGPR_TOP(64, 63);
     int64_t t = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     int64_t j = t >> 5;
     if (j >= n) return;
@@ -1632,12 +1683,13 @@ __global__ __launch_bounds__(TK_BLOCK) void k_expand_features(int64_t n, const u
 //               v = (value - ret)^2,  H = -sum p log p over the legal cards;
 //   loss = sum_i w_i (pi_i + vf v_i - ent H_i) / wsum.
 // dout = d loss / d out (bf16); part[block] = {sum w pi, sum w v, sum w H, 0} (f32, unscaled).
-__global__ __launch_bounds__(TK_BLOCK) void k_ppo_loss(int64_t n, const uint4 *__restrict__ out, const u64 *__restrict__ words,
+TK_KERNEL(TK_BLOCK, 256) void k_ppo_loss(int64_t n, const uint4 *__restrict__ out, const u64 *__restrict__ words,
                                                       const int64_t *__restrict__ act, const float *__restrict__ logp_old,
                                                       const float *__restrict__ adv, const float *__restrict__ ret,
                                                       const float *__restrict__ weight, float clip, float vf_coef,
                                                       float ent_coef, const float *__restrict__ inv_wsum_p, uint4 *__restrict__ dout,
                                                       float4 *__restrict__ part) {
+    TK_VGPR_TOP(256, 255);
     __shared__ float red[3][TK_BLOCK / 64];
     float inv_wsum = *inv_wsum_p;
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
@@ -2026,12 +2078,13 @@ __device__ __forceinline__ void policy_body(
     }
 }
 
-__global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
+__global__ __launch_bounds__(TK_BLOCK, 2) TK_VGPR_BUDGET(256) void k_policy_mlp(
     int64_t n, const ulonglong2 *__restrict__ s01, const ulonglong2 *__restrict__ s23, const u64 *__restrict__ obs,
     const u64 *__restrict__ gkey, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
     uint4 *__restrict__ features_out, ulonglong2 *__restrict__ feature_words_out, u64 *__restrict__ stamps) {
+    TK_VGPR_TOP(256, 255);
     policy_body<1>(n, s01, s23, obs, gkey, w1, b1, w2, b2, w3, b3, action, logp, value, features_out, feature_words_out, stamps,
                    nullptr);
 }
@@ -2041,15 +2094,16 @@ __global__ __launch_bounds__(TK_BLOCK, 2) void k_policy_mlp(
 // as two 128-game tiles side by side, leaves the sampled cards in LDS and then runs the step
 // kernel's play role on them (threads 0..255; same refill lists, same launch-parity protocol as
 // k_play); the workgroups after the play groups run the refill role.
-__global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
+__global__ __launch_bounds__(2 * TK_BLOCK, 2) TK_VGPR_BUDGET(256) void k_policy_step(
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,
     const u64 *__restrict__ obs_in, const __bf16 *__restrict__ w1, const float *__restrict__ b1,
     const __bf16 *__restrict__ w2, const float *__restrict__ b2, const __bf16 *__restrict__ w3,
     const float *__restrict__ b3, uint8_t *__restrict__ action, float *__restrict__ logp, float *__restrict__ value,
     ulonglong2 *__restrict__ feature_words_out, int16_t *__restrict__ reward, uint8_t *__restrict__ done,
     uint16_t *__restrict__ trick, u64 *__restrict__ obs_out, uint8_t *__restrict__ hist,
-    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *__restrict__ aux, Counters *__restrict__ cnt,
-    u64 *__restrict__ gkey, u64 *__restrict__ rlist, u32 *__restrict__ rcount) {
+    ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
+    u64 *__restrict__ gkey, u64 *rlist, u32 *rcount) {
+    TK_VGPR_TOP(256, 255);
     u32 count = launch_count(epoch);          // (in flight under the policy's first loads)
     if (blockIdx.x >= play_groups) {
         refill_role<false>(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
@@ -2083,10 +2137,11 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) void k_policy_step(
 // Workgroup = 64 slots x 4 seats: one thread per (slot, seat) builds its row's description, then the 256 threads
 // write the 64 x 4 x 54 floats of the workgroup as full lines.
 #define TG_SLOTS 64
-__global__ __launch_bounds__(256) void k_targets_ref(int64_t n, int T, const u64 *__restrict__ obs_before, const uint8_t *__restrict__ action,
+TK_KERNEL(256, 64) void k_targets_ref(int64_t n, int T, const u64 *__restrict__ obs_before, const uint8_t *__restrict__ action,
                                                     const uint16_t *__restrict__ trick, const uint8_t *__restrict__ done,
                                                     const int16_t *__restrict__ reward, const float *__restrict__ next_q, float factor,
                                                     float4 *__restrict__ dy, uint8_t *__restrict__ meta) {
+    TK_VGPR_TOP(64, 63);
     __shared__ uint2 mask_s[256];
     __shared__ float val_s[256];
     __shared__ u32 card_s[256];
@@ -2146,8 +2201,9 @@ __global__ __launch_bounds__(256) void k_targets_ref(int64_t n, int T, const u64
 
 #include "tarok_learner.inc"
 
-__global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
+TK_KERNEL(TK_BLOCK, 64) void k_counters(int64_t n, const Counters *__restrict__ cnt, u32 *__restrict__ ep,
                                                       int4 *__restrict__ score_sum) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     if (ep) ep[i] = cnt[i].episode;
@@ -2155,8 +2211,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_counters(int64_t n, const Counters
 }
 
 // canonical lanes for parity checks: H0-3, P0-3, TAL, META (tarok_env.h)
-__global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglong2 *__restrict__ s01,
+TK_KERNEL(TK_BLOCK, 64) void k_get_state(int64_t n, const ulonglong2 *__restrict__ s01,
                                                        const ulonglong2 *__restrict__ s23, u64 *__restrict__ out) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     Game g;
@@ -2187,9 +2244,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_get_state(int64_t n, const ulonglo
 // inverse of k_get_state: rebuild the packed pairs from canonical lanes (checkpoint restore,
 // hand-built positions).  Cards on the table go back to whoever played them, the un-owned
 // talon to where setup_game parks it.
-__global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__restrict__ in,
+TK_KERNEL(TK_BLOCK, 64) void k_set_state(int64_t n, const u64 *__restrict__ in,
                                                        ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23,
                                                        const Counters *__restrict__ cnt) {
+    TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
     u64 m = in[9 * n + i];
@@ -2229,6 +2287,69 @@ __global__ __launch_bounds__(TK_BLOCK) void k_set_state(int64_t n, const u64 *__
     g.B = seatc[2] | seatc[3];
     g.C = piles | on_table | unowned;
     store_game(g, s01, s23, i);
+}
+
+
+// ---------------------------------------------------------------------------
+// tarok_debug_refill_selftest: the refill role AS EACH STEP KERNEL COMPILES IT, fed with lists built by hand — every slot of
+// every group, `per_slot` episodes each, on both parities — and every line it writes compared with a straight re-deal by a
+// kernel of its own.  Round 3's corruption was a dealt-ahead game WRITTEN wrong by the refill loop of one build (a gfx950
+// erratum, see TK_VGPR_TOP); no test looked at the lines themselves, and only lists of several hundred entries — four
+// passes of the loop on full waves — showed it.  This is that test (tests/test_gpu_parity.py), for any build.
+__global__ __launch_bounds__(TK_BLOCK) TK_VGPR_BUDGET(64) void k_dbg_fill_lists(u64 *rlist, u32 *rcount, u32 per_slot, u32 ep0, u32 order) {
+    TK_VGPR_TOP(64, 63);
+    u32 g = blockIdx.x;
+    for (u32 idx = threadIdx.x; idx < per_slot * TK_BLOCK; idx += TK_BLOCK) {
+        u32 k = idx / TK_BLOCK, t = idx % TK_BLOCK;
+        if (order == 1) t = TK_BLOCK - 1 - t;
+        if (order == 2) t = (t * 37u + 11u) % TK_BLOCK;
+        u64 en = ((u64)(ep0 + 1 + k) << 32) | t;
+        rlist[((int64_t)g * 2 + 0) * TK_REFILL_CAP + idx] = en;
+        rlist[((int64_t)g * 2 + 1) * TK_REFILL_CAP + idx] = en;
+    }
+    if (threadIdx.x == 0) {
+        rcount[TK_RC(g, 0)] = per_slot * TK_BLOCK; rcount[TK_RC(g, 1)] = per_slot * TK_BLOCK;
+        rcount[TK_RC(g, 2)] = 0; rcount[TK_RC(g, 3)] = 0;
+    }
+}
+__global__ __launch_bounds__(TK_BLOCK) TK_VGPR_BUDGET(64) void k_dbg_clear_lines(Aux *aux, int64_t n) {
+    TK_VGPR_TOP(64, 63);
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int b = 0; b < TK_AHEAD; b++) {
+        AuxLine *ln = &aux[i].line[b];
+        ln->n01 = make_ulonglong2(0, 0); ln->n23 = make_ulonglong2(0, 0); ln->nkey = 0; ln->nep = 0xFFFFFFFFu;
+    }
+}
+// out[0] = lines that differ; out[1 + 6 r ..] = {slot, episode, x0 read, x0 expected, y0 read, y0 expected} of the first eight
+__global__ __launch_bounds__(TK_BLOCK) TK_VGPR_BUDGET(128) void k_dbg_check_lines(Aux *aux, int64_t n, u64 seed, u64 offset, int mix, u32 per_slot,
+                                                                                  u32 ep0, unsigned long long *out) {
+    TK_VGPR_TOP(128, 127);
+    int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (u32 k = 0; k < per_slot; k++) {
+        u32 episode = ep0 + 1 + k;
+        u64 key = game_key(seed, offset + (u64)i, (u64)episode);
+        u64 h0, h1, h2, h3, tal;
+        deal_thread(key, h0, h1, h2, h3, tal);
+        u32 c, d, kk;
+        sample_setup(key, mix, c, d, kk);
+        Game g;
+        setup_game(g, h0, h1, h2, h3, tal, c, d, kk);
+        g.epar = TK_LINE(episode); g.cprev = 0;
+        if (g.phase == TK_PHASE_EXCHANGE) bot_exchange(g, key);
+        ulonglong2 ea, eb;
+        pack(g, ea.x, ea.y, eb.x, eb.y);
+        const AuxLine *ln = &aux[i].line[TK_LINE(episode)];
+        ulonglong2 na = ln->n01, nb = ln->n23;
+        if (ea.x != na.x || ea.y != na.y || eb.x != nb.x || eb.y != nb.y || key != ln->nkey || ln->nep != episode) {
+            unsigned long long r = atomicAdd(&out[0], 1ULL);
+            if (r < 8) {
+                unsigned long long *o = out + 1 + 6 * r;
+                o[0] = (u64)i; o[1] = episode; o[2] = na.x; o[3] = ea.x; o[4] = nb.x; o[5] = eb.x;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2303,10 +2424,16 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     return TAROK_OK;
 }
 
+static void drop_graphs(tarok_env *e) {      // (behind a device synchronisation: nothing of theirs is queued any more)
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < e->n_graphs; k++) (void)hipGraphExecDestroy(e->graphs[k].exec);
+    e->n_graphs = 0;
+}
+
 void tarok_destroy(tarok_env *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     (void)hipFree(e->s01); (void)hipFree(e->s23); (void)hipFree(e->aux); (void)hipFree(e->cnt); (void)hipFree(e->nstale); (void)hipFree(e->gkey);
     (void)hipFree(e->rlist); (void)hipFree(e->rcount); (void)hipFree(e->elist); (void)hipFree(e->epoch); (void)hipFree(e->hist); (void)hipFree(e->adam_sumsq);
@@ -2317,11 +2444,25 @@ int64_t tarok_num_games(const tarok_env *e) { return e ? e->n : 0; }
 
 int tarok_set_option(tarok_env *e, int option, int value) {
     if (!e) return TAROK_EINVAL;
-    if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) e->refill_fan = (uint32_t)value;
-    else if (option == TAROK_OPT_LAZY_REFILL && (value == 0 || value == 1)) e->lazy_refill = (uint32_t)value;
-    else return TAROK_EINVAL;
-    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }      // (the cached graph holds the old launches)
-    return TAROK_OK;
+    if (option == TAROK_OPT_REFILL_FAN && value >= 1 && value <= TK_REFILL_FAN) {
+        if ((uint32_t)value != e->refill_fan && e->launched) {
+            // The fan sets the step launches' grid, and the device-side launch counters count workgroups of ONE grid size
+            // (launch_phase): behind launches of the old grid they would put workgroups of one launch into different
+            // phases.  So the change waits for everything queued, restarts the counters and empties all four refill lists
+            // of every group — their entries are only ever a hint: a line whose deal is dropped stays stale (its tag says
+            // so) until its slot reaches it, deals that game in place and lists all its lines again.
+            HIPCHK(hipSetDevice(e->device));
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32)));
+            HIPCHK(hipMemset(e->rcount, 0, TK_RC((e->n + TK_BLOCK - 1) / TK_BLOCK, 0) * sizeof(u32)));
+        }
+        e->refill_fan = (uint32_t)value;
+    } else if (option == TAROK_OPT_LAZY_REFILL && (value == 0 || value == 1)) {
+        // (safe between any two launches: with the option off every step launch empties the stretch lists unworked, so
+        // there is nothing on them when it comes back on, and entries dropped when it goes off only leave stale lines)
+        e->lazy_refill = (uint32_t)value;
+    } else return TAROK_EINVAL;
+    return TAROK_OK;      // (graphs instantiated for the old tuning stay cached under their own key: tarok_run_random)
 }
 
 static inline void launch_prefetch(tarok_env *e, hipStream_t s) {
@@ -2370,6 +2511,9 @@ int tarok_legal_actions(tarok_env *e, uint64_t *obs_out, int8_t *seat_out, void 
     return TAROK_OK;
 }
 
+// the diagnostics buffer for a kernel that writes `words` of it, or NULL (none registered, or too small)
+static inline u64 *stamps_for(const tarok_env *e, size_t words) { return (e->stamps && e->stamps_words >= words) ? e->stamps : nullptr; }
+
 // One play launch: play workgroups + the refill workgroups that work the previous launch's lists off.
 // cards = 1 (tarok_step, tarok_step_random): the one-card kernel k_step; more cards: the Bot-policy card loops
 // of k_play_wide.
@@ -2379,6 +2523,7 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
+    e->launched = 1;
     if (cards == 1) {
 #define TK_LAUNCH_STEP(R, Z)                                                                                             \
     hipLaunchKernelGGL((k_step<R, Z>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \
@@ -2392,7 +2537,8 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
 #define TK_LAUNCH_PLAY(H)                                                                                              \
     hipLaunchKernelGGL((k_play_wide<H>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, cards, stride, \
                        groups, e->epoch, fan, action_out, reward, done, trick, (u64 *)obs, e->hist, e->s01,            \
-                       e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, e->stamps)
+                       e->s23, e->aux, e->cnt, e->gkey, e->rlist, e->rcount, stamps)
+    u64 *stamps = stamps_for(e, 3 * (size_t)((e->n + 63) / 64));
     if (e->hist) TK_LAUNCH_PLAY(true); else TK_LAUNCH_PLAY(false);
 #undef TK_LAUNCH_PLAY
 }
@@ -2469,11 +2615,16 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
     hipStream_t s = (hipStream_t)stream;
     int64_t left = n_steps;
     if (graph_chunk > 0 && left >= graph_chunk) {
-        bool hit = e->gexec && e->g_fused == cards_per_launch && e->g_chunk == graph_chunk && e->g_flags == flags &&
-                   e->g_prefetch == prefetch_every &&
-                   e->g_action == action && e->g_reward == reward_out && e->g_done == done_out && e->g_obs == obs_out;
-        if (!hit) {
-            if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        hipGraphExec_t gexec = nullptr;
+        for (int k = 0; k < e->n_graphs && !gexec; k++) {
+            const tarok_env::GraphEntry &g = e->graphs[k];
+            if (g.fused == cards_per_launch && g.chunk == graph_chunk && g.flags == flags && g.prefetch == prefetch_every &&
+                g.action == action && g.reward == reward_out && g.done == done_out && g.obs == obs_out && g.stamps == e->stamps &&
+                g.fan == e->refill_fan && g.lazy == e->lazy_refill)
+                gexec = g.exec;
+        }
+        if (!gexec) {
+            if (e->n_graphs == TK_GRAPH_CACHE) drop_graphs(e);
             hipGraph_t graph = nullptr;
             HIPCHK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed));
             for (int k = 0; k < graph_chunk; k += unit) {
@@ -2481,14 +2632,14 @@ int tarok_run_random(tarok_env *e, int64_t n_steps, int cards_per_launch, int gr
                 if (prefetch_every && (k + unit) % prefetch_every == 0) launch_prefetch(e, e->cap_stream);
             }
             HIPCHK(hipStreamEndCapture(e->cap_stream, &graph));
-            hipError_t r = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+            hipError_t r = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
-            if (r != hipSuccess) { e->gexec = nullptr; g_last_hip = (int)r; return TAROK_EHIP; }
-            e->g_fused = cards_per_launch; e->g_chunk = graph_chunk; e->g_flags = flags; e->g_prefetch = prefetch_every;
-            e->g_action = action; e->g_reward = reward_out; e->g_done = done_out; e->g_obs = obs_out;
+            if (r != hipSuccess) { g_last_hip = (int)r; return TAROK_EHIP; }
+            e->graphs[e->n_graphs++] = {gexec, cards_per_launch, graph_chunk, flags, prefetch_every, action, reward_out, done_out,
+                                        obs_out, e->stamps, e->refill_fan, e->lazy_refill};
         }
         while (left >= graph_chunk) {
-            HIPCHK(hipGraphLaunch(e->gexec, s));
+            HIPCHK(hipGraphLaunch(gexec, s));
             left -= graph_chunk;
         }
     }
@@ -2510,11 +2661,59 @@ int tarok_rollout_random(tarok_env *e, uint32_t episode, int16_t *scores_out, in
     return TAROK_OK;
 }
 
-int tarok_debug_stamps(tarok_env *e, uint64_t *stamps) {
-    if (!e) return TAROK_EINVAL;
+int tarok_debug_stamps_sized(tarok_env *e, uint64_t *stamps, int64_t n_words) {
+    if (!e || n_words < 0 || (stamps && n_words == 0)) return TAROK_EINVAL;
     e->stamps = (u64 *)stamps;
-    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    e->stamps_words = stamps ? (size_t)n_words : 0;
+    return TAROK_OK;      // (graphs captured with another stamps pointer stay cached under their own key)
+}
+
+int tarok_debug_stamps(tarok_env *e, uint64_t *stamps) {      // the step kernels' size: [ceil(N/64), 3]
+    if (!e) return TAROK_EINVAL;
+    return tarok_debug_stamps_sized(e, stamps, stamps ? 3 * ((e->n + 63) / 64) : 0);
+}
+
+int tarok_debug_refill_selftest(tarok_env *e, int kind, int per_slot, uint32_t episode0, int order, int reps, uint64_t *report_out) {
+    if (!e || kind < 0 || kind > 3 || per_slot < 1 || per_slot > TK_AHEAD || order < 0 || order > 2 || reps < 1 || !report_out) return TAROK_EINVAL;
+#if TK_BLOCK != 256
+    return TAROK_EINVAL;
+#else
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t n = e->n;
+    const size_t rows = 4;
+    void *buf = nullptr;
+    unsigned long long *rep = nullptr;
+    HIPCHK(hipMalloc(&buf, rows * (size_t)n * (8 + 8 + 1 + 1) + 64));
+    hipError_t r = hipMalloc((void **)&rep, 49 * sizeof(unsigned long long));
+    if (r == hipSuccess) r = hipMemset(rep, 0, 49 * sizeof(unsigned long long));
+    if (r != hipSuccess) { (void)hipFree(buf); g_last_hip = (int)r; return TAROK_EHIP; }
+    uint64_t *obs = (uint64_t *)buf;
+    int16_t *reward = (int16_t *)(obs + rows * n);
+    uint8_t *action = (uint8_t *)(reward + rows * n * 4), *done = action + rows * n;
+    u32 groups = (u32)((n + TK_BLOCK - 1) / TK_BLOCK);
+    for (int it = 0; it < reps; it++) {
+        hipLaunchKernelGGL(k_dbg_clear_lines, grid_for(n), dim3(TK_BLOCK), 0, 0, e->aux, n);
+        hipLaunchKernelGGL(k_dbg_fill_lists, dim3(groups), dim3(TK_BLOCK), 0, 0, e->rlist, e->rcount, (u32)per_slot, episode0, (u32)order);
+        if (kind == 0) launch_play(e, true, 1, n, nullptr, action, reward, done, nullptr, obs, TAROK_AUTO_RESET, 0);            // k_step, Bot policy
+        else if (kind == 1) {                                                                                                  // k_step, cards given
+            hipLaunchKernelGGL(k_legal, grid_for(n), dim3(TK_BLOCK), 0, 0, n, e->s01, e->s23, (u64 *)obs, (int8_t *)nullptr);
+            launch_policy(e, obs, action, 0);
+            launch_play(e, false, 1, n, action, nullptr, reward, done, nullptr, obs, TAROK_AUTO_RESET, 0);
+        } else launch_play(e, true, kind == 2 ? 4 : 2, n, nullptr, action, reward, done, nullptr, obs, TAROK_AUTO_RESET, 0);    // k_play_wide
+        hipLaunchKernelGGL(k_dbg_check_lines, grid_for(n), dim3(TK_BLOCK), 0, 0, e->aux, n, e->seed, e->offset, e->mix, (u32)per_slot, episode0, rep);
+    }
+    r = hipDeviceSynchronize();
+    if (r == hipSuccess) r = hipMemcpy(report_out, rep, 49 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    // the lists and lines of the env are the test's now: empty them all and deal every slot's lines afresh
+    if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
+    if (r == hipSuccess) {
+        hipLaunchKernelGGL(k_dbg_clear_lines, grid_for(n), dim3(TK_BLOCK), 0, 0, e->aux, n);
+        r = hipDeviceSynchronize();
+    }
+    (void)hipFree(buf); (void)hipFree(rep);
+    if (r != hipSuccess) { g_last_hip = (int)r; return TAROK_EHIP; }
     return TAROK_OK;
+#endif
 }
 
 int tarok_observe(tarok_env *e, void *features_out, void *stream) {
@@ -2589,7 +2788,7 @@ int tarok_policy_mlp(tarok_env *e, const void *w1, const float *b1, const void *
     dim3 grid((unsigned)((e->n + PM_M - 1) / PM_M));
     hipLaunchKernelGGL(k_policy_mlp, grid, dim3(TK_BLOCK), 0, (hipStream_t)stream, e->n, e->s01, e->s23, (const u64 *)obs,
                        e->gkey, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3, action_out, logp_out,
-                       value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, e->stamps);
+                       value_out, (uint4 *)features_out, (ulonglong2 *)feature_words_out, stamps_for(e, 8 * (size_t)grid.x));
     HIPCHK(hipGetLastError());
     return TAROK_OK;
 #endif
@@ -2607,6 +2806,7 @@ int tarok_policy_step(tarok_env *e, const void *w1, const float *b1, const void 
     u32 groups = (u32)((e->n + TK_BLOCK - 1) / TK_BLOCK);
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
+    e->launched = 1;
     hipLaunchKernelGGL(k_policy_step, grid, dim3(2 * TK_BLOCK), 0, (hipStream_t)stream, e->n, e->seed, e->offset, e->mix, flags,
                        groups, e->epoch, fan, (const u64 *)obs, (const __bf16 *)w1, b1, (const __bf16 *)w2, b2, (const __bf16 *)w3, b3,
                        action_out, logp_out, value_out, (ulonglong2 *)feature_words_out, reward_out, done_out, trick_out,
@@ -2684,8 +2884,8 @@ int tarok_learn_chain(tarok_env *e, int64_t B, const uint64_t *feature_words, co
     a.Xw = (ulonglong2 *)Xw;
     a.H1 = (uint4 *)H1; a.H2 = (uint4 *)H2; a.dH2 = (uint4 *)dH2; a.dH1 = (uint4 *)dH1; a.dOut = (uint2 *)dOut;
     a.part = (float4 *)scratch;
-    a.stamps = e->stamps;
     unsigned blocks = (unsigned)((B + LN_M - 1) / LN_M);
+    a.stamps = stamps_for(e, 8 * (size_t)blocks);       // (eight stamps per workgroup: a buffer sized for the step kernels gets none)
     hipLaunchKernelGGL(k_learn_chain, dim3(blocks), dim3(LN_CHAIN_THREADS), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_learn_terms, dim3(1), dim3(TK_BLOCK), 0, (hipStream_t)stream, (int)blocks, (const float4 *)scratch,
                        (float4 *)terms_out, (float4 *)running);

@@ -88,6 +88,24 @@ class TarokVecEnv:
             self.trick = None     # allocated by step(..., tricks=True)
 
     # ------------------------------------------------------------------
+    def set_option(self, refill_fan=None, lazy_refill=None):
+        """Launch tuning (tarok_set_option) at any point of a run; results never depend on it.  A change of the refill fan
+        after the first step launch synchronises the device (include/tarok_env.h)."""
+        if refill_fan is not None:
+            _native.check(self.L.tarok_set_option(self._h, K.OPT_REFILL_FAN, int(refill_fan)))
+        if lazy_refill is not None:
+            _native.check(self.L.tarok_set_option(self._h, K.OPT_LAZY_REFILL, int(lazy_refill)))
+
+    def refill_selftest(self, kind, per_slot, episode0=100, order=0, reps=1):
+        """tarok_debug_refill_selftest (tests only; reset() afterwards): (wrong lines, [first records])."""
+        import numpy as np
+        rep = np.zeros(49, np.uint64)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _native.check(self.L.tarok_debug_refill_selftest(self._h, int(kind), int(per_slot), int(episode0), int(order), int(reps),
+                                                             rep.ctypes.data))
+        return int(rep[0]), rep[1:].reshape(8, 6)[: min(8, int(rep[0]))]
+
     def close(self):
         if self._h is not None:
             torch.cuda.synchronize(self.device)

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(libpath):
         assert hasattr(L, n), "libtarokenv.so does not export %s" % n
     assert set(names) == set(_native.SYMBOLS)
     L.tarok_abi_version.restype = ctypes.c_int
-    assert L.tarok_abi_version() == 4
+    assert L.tarok_abi_version() == 5
     L.tarok_strerror.restype = ctypes.c_char_p
     assert L.tarok_strerror(0) == b"ok" and b"argument" in L.tarok_strerror(-1)
 

@@ -1061,6 +1061,90 @@ def test_launch_kinds_mixed_at_full_size_vs_oracle(T, O, S, lazy):
     env.close()
 
 
+def _mixed_segments(env, rnd, target, between=None):
+    """tools/soak_mixed.py's sequence: one-card stretches (graph-replayed, eager, the two-kernel path) cut by multi-card
+    launches, no host synchronisation in between; `between(segment number)` may change the env's launch tuning."""
+    steps, seg = 0, 0
+    while steps < target:
+        kind = rnd.choice(["random", "two", "eager", "krog"], p=[0.35, 0.3, 0.15, 0.2])
+        if kind == "random":
+            k = int(rnd.choice([16, 48, 80, 112])); env.run_random(k, cards_per_launch=1, graph_chunk=16, auto_reset=True)
+        elif kind == "two":
+            k = int(rnd.choice([20, 60, 100])); env.run_random(k, cards_per_launch=0, graph_chunk=20, auto_reset=True)
+        elif kind == "eager":
+            k = int(rnd.randint(1, 23))
+            for _ in range(k):
+                env.step_random(auto_reset=True)
+        else:
+            k = int(rnd.choice([4, 8, 28, 48, 128])); env.krog_random(k, auto_reset=True)
+        steps += k; seg += 1
+        if between:
+            between(seg)
+    return steps
+
+
+def _assert_equals_oracle(env, O, S, seed, n, steps):
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
+    ep, ss = env.counters()
+    assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
+    assert (env.state() == ref["lanes"]).all()
+    assert (env.obs_words.cpu().numpy().view(np.uint64) == ref["obs"]).all()
+
+
+@pytest.mark.parametrize("lazy,target", [(None, 6000), (0, 3000)])
+def test_mixed_launch_soak_sequences_that_caught_the_refill_bug(T, O, S, lazy, target):
+    """The two sequences of tools/soak_mixed.py at which round 3's failing refill-role builds went wrong (65,536 games:
+    6,008 lock-steps with the bulk deals on, 3,058 with them off; those builds differed from the oracle in hundreds of
+    slots here — profiles/r04_refill_soak_matrix.txt).  The cause was a dealt-ahead game written wrong by the refill loop
+    (a gfx950 erratum the build now rules out statically: tests/test_isa_check.py); this is the end-to-end check."""
+    n, seed = 65536, 11
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
+    env.reset()
+    steps = _mixed_segments(env, np.random.RandomState(n % 1000 + target), target)
+    _assert_equals_oracle(env, O, S, seed, n, steps)
+    env.close()
+
+
+def test_launch_tuning_changed_in_the_middle_of_a_mixed_run(T, O, S):
+    """tarok_set_option between segments of a mixed run: the refill fan 1 -> 8 -> 3 -> 1 (each change restarts the env's
+    launch counters and empties its refill lists behind a device synchronisation: the lines whose deal was dropped are
+    dealt by their slots) and the bulk deals on -> off -> on; 65,536 games, ~2,400 lock-steps, all slots vs the oracle."""
+    n, seed, target = 65536, 11, 2400
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL)
+    env.reset()
+    fans, lazies = [8, 3, 1, 8, 1], [0, 1, 0, 1]
+    def between(seg):
+        if seg % 7 == 3:
+            env.set_option(refill_fan=fans[(seg // 7) % len(fans)])
+        if seg % 5 == 2:
+            env.set_option(lazy_refill=lazies[(seg // 5) % len(lazies)])
+    steps = _mixed_segments(env, np.random.RandomState(77), target, between)
+    _assert_equals_oracle(env, O, S, seed, n, steps)
+    with pytest.raises(Exception):
+        env.set_option(refill_fan=9)
+    with pytest.raises(Exception):
+        env.set_option(lazy_refill=2)
+    env.close()
+
+
+@pytest.mark.parametrize("n,lazy", [(65536, None), (65536, 0), (20000, None), (1 << 20, None)])
+def test_refill_role_of_every_step_kernel_deals_its_lists_right(T, S, n, lazy):
+    """tarok_debug_refill_selftest: the refill role as k_step (Bot policy / cards given, with and without the bulk-deal
+    code) and k_play_wide compile it, fed with hand-built lists — every slot of every group, 1 / 4 / 14 entries per slot
+    (one to fourteen passes of its loop on full waves), three list orders — and every line compared with a re-deal by a
+    separate kernel.  Round 3's failing builds wrote 0.6 % of the lines wrong in exactly this setting (4 entries per
+    slot; profiles/r04_refill_harness.txt) while every other test passed."""
+    env = T.TarokVecEnv(n, seed=11, mix=S.MIX_ALL, lazy_refill=lazy)
+    env.reset()
+    combos = [(0, 1, 0), (0, 4, 0), (0, 14, 2), (1, 4, 1), (1, 14, 0), (2, 4, 0), (2, 14, 2), (3, 14, 1)]
+    if n > (1 << 18):
+        combos = [(0, 14, 0), (1, 4, 2), (2, 14, 0)]
+    for kind, per_slot, order in combos:
+        wrong, recs = env.refill_selftest(kind, per_slot, episode0=100 + 20 * per_slot, order=order, reps=3)
+        assert wrong == 0, "kind %d, %d entries per slot, order %d: %d wrong lines, first %s" % (kind, per_slot, order, wrong, recs[:2].tolist())
+    env.close()
+
+
 def test_config1_single_klop_game_through_the_main_equivalent(T, O, S):
     """BASELINE config 1: ONE 4-player Klop game (the reference supports 4 players only,
     SURVEY §0) driven through the build's main-equivalent with reference-shaped players;

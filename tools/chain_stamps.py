@@ -11,7 +11,7 @@ sp = selfplay.SelfPlay(env, hidden=256, seed=0)
 sp.iterate(T=48, epochs=1, minibatches=8)
 blocks = (393216 + 95) // 96
 st = torch.zeros((blocks, 8), dtype=torch.int64, device="cuda")
-_native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
+_native.check(env.L.tarok_debug_stamps_sized(env._h, C.c_void_p(st.data_ptr()), st.numel()))
 buf = sp.collect(48)
 sp.update_fused(buf, epochs=1, minibatches=8)
 torch.cuda.synchronize()

@@ -48,7 +48,7 @@ import ctypes as C, numpy as np
 from tarok_amd import _native
 nb = (n + 127) // 128
 st = torch.zeros((max(nb * 8, (n + 63) // 64 * 3), ), dtype=torch.int64, device="cuda")
-_native.check(env.L.tarok_debug_stamps(env._h, C.c_void_p(st.data_ptr())))
+_native.check(env.L.tarok_debug_stamps_sized(env._h, C.c_void_p(st.data_ptr()), st.numel()))
 env.policy_mlp(w, words, a, lp, v)
 torch.cuda.synchronize()
 _native.check(env.L.tarok_debug_stamps(env._h, None))
