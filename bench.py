@@ -227,8 +227,12 @@ def main():
         (e or env).run_random(plan["lock_steps"], cards_per_launch=plan["cards"], graph_chunk=plan["graph_chunk"], auto_reset=True, **kw)
 
     def timed(plan, events=None, e=None):
-        """barrier + synchronize, the plan's launches, synchronize + barrier; MAX over ranks of the wall time.
-        events: (ev0, ev1, stream) recorded on the launch stream around the same launches."""
+        """barrier + synchronize, the plan's launches, synchronize, [clock stops], barrier; MAX over ranks of the wall time.
+        The clock stops when THIS rank's launches have drained, before the trailing barrier: the path has no collective,
+        and a barrier of the process group (tens to hundreds of microseconds) inside a region of a millisecond would be
+        read as bad scaling (round 3's two-rank rehearsal: wall 2.65 ms against 1.10 ms of HIP events).  The slowest
+        rank's time is the job's: MAX over ranks.  events: (ev0, ev1, stream) recorded on the launch stream around the
+        same launches."""
         sharding.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -238,8 +242,9 @@ def main():
         if events:
             events[1].record(events[2])
         torch.cuda.synchronize(dev)
-        sharding.barrier()
         dt = time.perf_counter() - t0
+        sharding.barrier()
+        timed.last_rank_wall = dt
         return sharding.max_over_ranks([dt])[0]
 
     def leg(cards, passes, e=None):
@@ -267,6 +272,9 @@ def main():
     ev[1].record(stream)
     dt = timed(plan, ev)
     ev_ms = ev[0].elapsed_time(ev[1])
+    wall_per_rank = sharding.gather_over_ranks(timed.last_rank_wall)
+    ev_per_rank = sharding.gather_over_ranks(ev_ms)
+    pg = sharding.group_info()
     env_steps = n * plan["lock_steps"] * world_size
     value = env_steps / dt
     # 5 repeats over the seeds {0, 1, 2}, median (min-max).  `value` stays the first region (seed 0: the
@@ -299,8 +307,11 @@ def main():
                                                                             n * plan["lock_steps_per_launch"]),
         "lock_steps_timed": plan["lock_steps"], "us_per_lock_step": dt / plan["lock_steps"] * 1e6,
         "timed_region": {"wall_ms_max_over_ranks": dt * 1e3, "hip_event_ms_rank0": ev_ms,
-                         "note": "value uses the wall time (barrier + synchronize on both sides); the HIP events bracket the "
-                                 "same launches on the launch stream"},
+                         "wall_ms_per_rank": [w * 1e3 for w in wall_per_rank], "hip_event_ms_per_rank": ev_per_rank,
+                         "process_group": pg, "rccl_ranks_seen": pg["world_size"] if pg["backend"] == "nccl" else 0,
+                         "note": "barrier + synchronize before the region; every rank's clock stops when its own launches "
+                                 "have drained (synchronize), a barrier follows OUTSIDE the clock; value uses the MAX over "
+                                 "ranks of that wall time; the HIP events bracket the same launches on the launch stream"},
         "config": {"workload": "configs[2]: %d parallel envs per GPU, mixed Klop/Berac/Navadna contracts "
                                "(1/3 Klop, 1/3 Berac incl. 1/2 open, 1/3 Navadna+Solo over 7 types), uniform random policy, "
                                "auto-reset (every slot live in every step)" % n,

@@ -61,7 +61,11 @@ def build(force=False, verbose=False):
         try:
             if force or needs_build():
                 tmp = "%s.tmp.%d" % (LIB_PATH, os.getpid())
+                # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in scalar registers with the dispatch
+                # instead of behind a scalar load at the top of the kernel (0.1-0.2 us of every latency-bound launch:
+                # profiles/r04_ab_step.txt); firmware without the feature runs the kernels' own load prologue
                 cmd = [hipcc_path(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
+                       "-mllvm", "-amdgpu-kernarg-preload-count=16",
                        "-I", os.path.join(ROOT, "include"), "-o", tmp, SRC]
                 if verbose:
                     print(" ".join(cmd))

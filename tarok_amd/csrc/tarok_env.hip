@@ -46,7 +46,10 @@
 // list lengths: one 128-byte line per (play workgroup, parity) — neighbouring workgroups run on
 // different XCDs, whose L2s are not coherent: two of them must never write into one line
 #define TK_RC(group, k) ((((size_t)(group)) * 4 + (k)) * 32)     // k = 0, 1: the per-launch lists by parity; 2, 3: the one-card step's stretch lists
-#define TK_BULK_CAP (4 * TK_BLOCK)  // entries of a stretch list: a slot ends at most four games in TK_BULK_EVERY = 16 one-card launches
+#ifndef TK_BULK_EVERY
+#define TK_BULK_EVERY 32u          // one-card launches per stretch (a power of two; see launch_count): the stretch lists are dealt in bulk this often
+#endif
+#define TK_BULK_CAP ((TK_BULK_EVERY / 4) * TK_BLOCK)  // entries of a stretch list: a game is at least four cards long, one card per launch
 
 #ifndef TK_AHEAD
 #define TK_AHEAD TAROK_GAMES_AHEAD  // next-game lines per slot (<= 15: epar and cprev are 4 bits each)
@@ -111,8 +114,8 @@ struct tarok_env {
     u64 *rlist;              // refill lists [play workgroups][2 parities][TK_REFILL_CAP]: episode<<32 | slot in group
     u32 *rcount;             // [play workgroups][4] list lengths, one 128-byte line each (TK_RC)
     u64 *elist;              // the one-card step's stretch lists [play workgroups][2][TK_BULK_CAP] (refill_role)
-    u32 *epoch;              // TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches started so far (see
-                             // launch_count): the parity of the refill list the running launch writes (it works the other one off)
+    u32 *epoch;              // 2 x TK_EPOCH_SHARDS counters, 128 bytes apart: workgroups of step launches of either kind started so
+                             // far (launch_count): the parity of the refill list the running launch writes (it works the other one off)
     uint32_t refill_fan;     // play workgroups per refill workgroup (1..TK_REFILL_FAN)
     uint32_t lazy_refill;    // the one-card step lists emptied lines for a bulk deal every TK_BULK_EVERY launches (refill_role)
     int n_cus;               // compute units of the device (k_learn_dw's grid), 0 = not asked yet
@@ -308,10 +311,10 @@ TK_KERNEL(TK_BLOCK, 64) void k_policy(int64_t n, const u64 *__restrict__ obs,
     TK_VGPR_TOP(64, 63);
     int64_t i = (int64_t)blockIdx.x * TK_BLOCK + threadIdx.x;
     if (i >= n) return;
-    u64 o = obs[i];
+    u64 o = obs[i], key = gkey[i];     // (the key asked for WITH the observation word, not behind it: one memory round trip)
     u64 m = o & TAROK_OBS_MASK;
     u32 a = 255;
-    if (m) a = policy_action(gkey[i], (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m);
+    if (m) a = policy_action(key, (u32)(o >> TAROK_OBS_STEP_SHIFT) & 63u, m);
     action[i] = (uint8_t)a;
 }
 
@@ -346,49 +349,6 @@ TK_KERNEL(TK_BLOCK, 64) void k_policy_x4(int64_t n, const u64 *__restrict__ obs,
     }
 }
 
-// Launch number modulo TK_PHASES (see the file header) without a host counter.  The workgroups of step launches are
-// counted as they START, modulo TK_PHASES times their number G per launch (every step launch of an env has the same
-// grid): launch L begins with the count at (L mod TK_PHASES) * G; every workgroup reads the count together with its
-// first loads (launch_count: nothing waits for it alone) and adds itself afterwards (launch_counted: a wrapping
-// increment WITHOUT a return value, behind the read in the lane's program order — it completes somewhere under the
-// card loop).  At any read at most G - 1 workgroups of the running launch have added themselves, so the count is still
-// in launch L's band: phase = count / G.  The kernel boundary drains the adds before the next launch reads.  The
-// count is kept in TK_EPOCH_SHARDS separate counters (one 128-byte line each), workgroup b using counter b mod
-// TK_EPOCH_SHARDS with G_s = the number of such workgroups: the argument holds for every counter on its own, and the
-// adds do not queue up behind each other — ONE counter took 512 same-address atomics per launch at 65,536 games,
-// serialised at the memory side: +3.4 us on every launch, wherever in the kernel they were issued
-// (profiles/r02_ab_launch_parity.txt).
-// The low bit of the phase is the parity of the refill list the launch writes; the one-card step also works the
-// next-game lines its slots emptied off in bulk, once per TK_BULK_EVERY launches (step_role, refill_role).
-#define TK_EPOCH_SHARDS 256
-#define TK_PHASES 32u
-#define TK_BULK_EVERY 16u
-__device__ __forceinline__ u32 launch_shard_size() {      // workgroups of this grid that share this workgroup's counter
-    return (gridDim.x + TK_EPOCH_SHARDS - 1 - (blockIdx.x % TK_EPOCH_SHARDS)) / TK_EPOCH_SHARDS;
-}
-__device__ __forceinline__ u32 launch_count(const u32 *epoch) {
-    return __hip_atomic_load(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// count / G_s: a float estimate (count < TK_PHASES * G_s is exact as a float for any grid a launch can have; the half added
-// to the count keeps the quotient away from the integers) put right by one exact integer step either way
-__device__ __forceinline__ u32 launch_phase(u32 count) {
-    // (the count is the same in every lane, and the compiler knows: without this fence it moves the quotient — and the wait
-    // for the count's load — to the top of the kernel, ahead of the state loads: +4 us per launch at 4 M games)
-    asm volatile("" : "+v"(count));
-    u32 g = launch_shard_size();
-    u32 q = (u32)(((float)count + 0.5f) * __builtin_amdgcn_rcpf((float)g));
-    q -= (q * g > count) ? 1u : 0u;
-    q += ((q + 1u) * g <= count) ? 1u : 0u;
-    return q;
-}
-__device__ __forceinline__ u32 launch_parity(u32 count) { return launch_phase(count) & 1u; }
-// call after launch_count in program order — one lane's read and add of one address stay in that order — behind a barrier
-// that every wave of the workgroup passes after ITS read of the count (refill_role), and before the first use of its value: the add counts as an outstanding memory operation of the wave, and issued only once the
-// count has arrived it adds a memory-side round trip to the life of every step wave (+4 us per launch at 4 M games)
-__device__ __forceinline__ void launch_counted(u32 *epoch) {
-    if (threadIdx.x == 0) (void)atomicInc(epoch + 32 * (blockIdx.x % TK_EPOCH_SHARDS), TK_PHASES * launch_shard_size() - 1u);
-}
-
 // WHAT WORKGROUPS HAND EACH OTHER, AND THROUGH WHICH CACHE (DESIGN.md §3 has the table).  Five buffers are written by one
 // workgroup and read by another: the next-game lines (`aux`: refill role -> play / step role), the per-launch refill lists
 // and their lengths (`rlist`, `rcount[0..1]`: play / step role -> refill role), the stretch lists and their lengths (`elist`,
@@ -401,6 +361,69 @@ __device__ __forceinline__ void launch_counted(u32 *epoch) {
 // read with an agent-scope atomic load (tk_ld: a vector load that misses the L1), and `epoch` — the one buffer read and
 // written within a launch — only with agent-scope atomics.
 template <class T> __device__ __forceinline__ T tk_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Launch number modulo TK_PHASES (see the file header) without a host counter.  The workgroups of step launches are
+// counted as they START, modulo TK_PHASES times their number G per launch: launch L begins with the count at
+// (L mod TK_PHASES) * G; every workgroup reads the count together with its first loads (launch_count: nothing waits for
+// it alone) and adds itself afterwards (launch_counted: a wrapping increment WITHOUT a return value, behind the read in
+// the lane's program order — it completes somewhere under the card loop).  At any read at most G - 1 workgroups of the
+// running launch have added themselves, so the count is still in launch L's band: phase = count / G.  The kernel boundary
+// drains the adds before the next launch reads.  The count is kept in TK_EPOCH_SHARDS separate counters (one 128-byte
+// line each), workgroup b using counter b mod TK_EPOCH_SHARDS with G_s = the number of such workgroups: the argument
+// holds for every counter on its own, and the adds do not queue up behind each other — ONE counter took 512 same-address
+// atomics per launch at 65,536 games, serialised at the memory side: +3.4 us on every launch, wherever in the kernel they
+// were issued (profiles/r02_ab_launch_parity.txt).
+// An env has step launches of TWO grid sizes (round 4): KIND 0, the one-card step of small batches (k_step<., true>):
+// `groups` workgroups, each of which plays its group's card and then works its OWN group's refill lists off — at 65,536
+// games the 256 refill workgroups of the other kind, idle in fifteen launches of sixteen, cost every launch ~0.9 us
+// (profiles/r04_ab_step.txt); KIND 1, every other step launch (k_play_wide, k_policy_step, the streaming k_step):
+// groups + ceil(groups / fan) workgroups, play and refill roles side by side.  Each kind counts ITS launches in its own
+// set of counters as above, and a workgroup of kind k reads, beside its own counter, one counter of the other kind — at
+// rest during this launch: exactly (launches of that kind mod TK_PHASES) * its shard size.  The launch number is the sum.
+// The low bit of the phase is the parity of the refill list the launch writes; the one-card step also works the
+// next-game lines its slots emptied off in bulk, once per TK_BULK_EVERY launches (step_role, refill_role).
+#define TK_EPOCH_SHARDS 256
+#define TK_EPOCH_WORDS (32 * TK_EPOCH_SHARDS)      // u32 words of one kind's counters (one 128-byte line per counter)
+#define TK_PHASES (2u * TK_BULK_EVERY)
+static_assert((TK_BULK_EVERY & (TK_BULK_EVERY - 1)) == 0 && TK_BULK_EVERY >= 4 && TK_BULK_EVERY + 1 <= 4 * (TK_AHEAD - 1),
+              "a line is dealt at most TK_BULK_EVERY + 1 launches after it was emptied and is needed again TK_AHEAD - 1 games (four launches each, at least) after that");
+struct TkCount { u32 own, other; };
+__device__ __forceinline__ u32 tk_shard_size(u32 grid, u32 shard) { return (grid + TK_EPOCH_SHARDS - 1 - shard) / TK_EPOCH_SHARDS; }
+// the other kind's grid, and the counter of it this workgroup reads (one that exists: kind 0's grid is the smaller one)
+template <int KIND> __device__ __forceinline__ u32 tk_other_grid(u32 groups, u32 fan) { return KIND == 0 ? groups + (groups + fan - 1) / fan : groups; }
+template <int KIND> __device__ __forceinline__ u32 tk_other_shard(u32 groups) { return (KIND == 0 ? blockIdx.x : blockIdx.x % groups) % TK_EPOCH_SHARDS; }
+template <int KIND> __device__ __forceinline__ TkCount launch_count(const u32 *epoch, u32 groups) {
+    TkCount c;
+    c.own = tk_ld(epoch + KIND * TK_EPOCH_WORDS + 32 * (blockIdx.x % TK_EPOCH_SHARDS));
+    c.other = tk_ld(epoch + (1 - KIND) * TK_EPOCH_WORDS + 32 * tk_other_shard<KIND>(groups));
+    return c;
+}
+// count / G_s: a float estimate (count < TK_PHASES * G_s is exact as a float for any grid a launch can have; the half added
+// to the count keeps the quotient away from the integers) put right by one exact integer step either way
+__device__ __forceinline__ u32 tk_div_small(u32 count, u32 g) {
+    u32 q = (u32)(((float)count + 0.5f) * __builtin_amdgcn_rcpf((float)g));
+    q -= (q * g > count) ? 1u : 0u;
+    q += ((q + 1u) * g <= count) ? 1u : 0u;
+    return q;
+}
+template <int KIND> __device__ __forceinline__ u32 launch_phase(TkCount c, u32 groups, u32 fan) {
+    // (the counts are the same in every lane, and the compiler knows: without this fence it moves the quotients — and the wait
+    // for the counts' loads — to the top of the kernel, ahead of the state loads: +4 us per launch at 4 M games)
+    asm volatile("" : "+v"(c.own), "+v"(c.other));
+    u32 own = tk_div_small(c.own, tk_shard_size(gridDim.x, blockIdx.x % TK_EPOCH_SHARDS));
+    u32 other = tk_div_small(c.other, tk_shard_size(tk_other_grid<KIND>(groups, fan), tk_other_shard<KIND>(groups)));
+    return (own + other) % TK_PHASES;
+}
+// call after launch_count in program order — one lane's read and add of one address stay in that order — behind a barrier
+// that every wave of the workgroup passes after ITS read of the count (were this the last workgroup of its counter to add,
+// a wave that read after the add would see the next launch's band), and before the first use of the count's value: the add
+// counts as an outstanding memory operation of the wave, and issued only once the count has arrived it adds a memory-side
+// round trip to the life of every step wave (+4 us per launch at 4 M games)
+template <int KIND> __device__ __forceinline__ void launch_counted(u32 *epoch) {
+    if (threadIdx.x == 0)
+        (void)atomicInc(epoch + KIND * TK_EPOCH_WORDS + 32 * (blockIdx.x % TK_EPOCH_SHARDS),
+                        TK_PHASES * tk_shard_size(gridDim.x, blockIdx.x % TK_EPOCH_SHARDS) - 1u);
+}
 
 // The step kernels.  One launch plays `cards` cards of every game:
 //   k_step (step_role), cards = 1: tarok_step — the card comes from `action_in` (an external policy) — and
@@ -432,12 +455,17 @@ template <class T> __device__ __forceinline__ T tk_ld(const T *p) { return __hip
 // of each such stretch works the previous stretch's list off here, on dense lanes, in one go.  A line waits for its
 // deal at most TK_BULK_EVERY launches and is not needed again before thirteen more games of its slot have
 // ended (>= 52 launches); lines a slot must not meet half written — the fourteen of a slot that dealt a game in place —
-// stay on the per-launch lists.  !BULK (k_play_wide, k_policy_step: slots there can take a line per trick): the
-// stretch lists of the workgroup's groups are emptied unworked — those lines stay stale until their slot comes round
-// to them, deals that game in place and lists all fourteen.
+// stay on the per-launch lists.  A BULK launch is of kind 0 (launch_count): it has no refill workgroups — the workgroup
+// that has just played its group's card runs this role for that group alone (fan 1, rblock = its group), so the count
+// has been read and counted by the step role already.  !BULK (kind 1: k_play_wide, k_policy_step, the streaming k_step;
+// slots there can take a line per trick): the stretch lists of the workgroup's groups are emptied unworked — those lines
+// stay stale until their slot comes round to them, deals that game in place and lists all fourteen.
 template <bool BULK>
 __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u64 seed, u64 offset, int mix, u32 play_groups,
-                                        u32 count, u32 *epoch, u32 fan, bool bulk_on, Aux *aux, u64 *rlist, u32 *rcount, u64 *elist) {
+                                        TkCount count, u32 *epoch, u32 fan, bool bulk_on, Aux *aux, u64 *rlist, u32 *rcount, u64 *elist) {
+    constexpr int KIND = BULK ? 0 : 1;
+    const u32 kind_fan = fan;            // (the env's fan: what the other kind's grid is made of)
+    if (BULK) fan = 1;                   // the workgroup's own group
     u32 g0 = rblock * fan;
     // every thread loads the two per-launch lengths of every group itself, the stretch lists' lengths only in the pass that
     // works them off.  (Round 3 shipped this form because shorter ones — all four lengths with one load per wave, sums in
@@ -455,9 +483,11 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
     // of the kernel; were this the last workgroup of its counter to add, a wave that read after the add would see the next
     // launch's band: the wrong parity, the list the running launch is writing).  The barrier puts every wave's read into the
     // memory pipe ahead of the add; step_role and play_role add behind their first barrier as well.
-    __syncthreads();
-    launch_counted(epoch);
-    const u32 phase = launch_phase(count), par = phase & 1u;
+    if (!BULK) {
+        __syncthreads();
+        launch_counted<KIND>(epoch);
+    }
+    const u32 phase = launch_phase<KIND>(count, play_groups, kind_fan), par = phase & 1u;
     if (!BULK) {                 // empty the stretch lists
         if (tid < 2 * fan && g0 + tid / 2 < play_groups) rcount[TK_RC(g0 + tid / 2, 2 + (tid & 1))] = 0u;
     }
@@ -512,7 +542,7 @@ __device__ __forceinline__ void refill_role(u32 rblock, u32 tid, u32 nthreads, u
 template <bool HIST>
 __device__ __forceinline__ void play_role(
     u32 group, u32 tid,
-    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, u32 count, u32 *epoch,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, int cards, int64_t stride, TkCount count, u32 *epoch, u32 play_groups, u32 fan,
     uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
@@ -611,8 +641,8 @@ __device__ __forceinline__ void play_role(
         }
     }
     TK_WAIT_LOADS();                        // nothing in flight when the loop starts (see above)
-    u32 par = launch_parity(count);         // (`count` was requested before the state: it has arrived with it)
-    launch_counted(epoch);
+    u32 par = launch_phase<1>(count, play_groups, fan) & 1u;     // (`count` was requested before the state: it has arrived with it)
+    launch_counted<1>(epoch);
     g.cprev = 0;
     u32 consumed = 0;                       // games swapped in / dealt during this launch
 #ifdef TK_EVENT_STAMPS                      // diagnostics build (tools/ev_probe.py): per-wave event counts
@@ -954,14 +984,14 @@ __device__ __forceinline__ void play_role(
 template <bool HIST>
 TK_KERNEL(TK_BLOCK, 168) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_play_wide(TK_PLAY_ARGS) {
     TK_VGPR_TOP(168, 167);
-    u32 count = launch_count(epoch);
+    TkCount count = launch_count<1>(epoch, play_groups);
     if (blockIdx.x >= play_groups)
         refill_role<false>(blockIdx.x - play_groups, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
     else {
 #ifdef TK_PLAY_PRIO                          // diagnostics build: wave priority of the play role (no effect: profiles/r02_ab_lone_wave_rewrite.txt)
         __builtin_amdgcn_s_setprio(TK_PLAY_PRIO);
 #endif
-        play_role<HIST>(blockIdx.x, threadIdx.x, n, seed, offset, mix, flags, cards, stride, count, epoch,
+        play_role<HIST>(blockIdx.x, threadIdx.x, n, seed, offset, mix, flags, cards, stride, count, epoch, play_groups, fan,
                         action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, stamps);
     }
 }
@@ -1020,7 +1050,7 @@ __device__ __forceinline__ void deal_in_place_wave(bool deal_here, Game &gd, u64
 template <bool RANDOM, bool LAZY>
 __device__ __forceinline__ void step_role(
     u32 group, u32 tid, bool active, u32 a_reg, bool lazy_on,
-    int64_t n, u64 seed, u64 offset, int mix, int flags, u32 count, u32 *epoch,
+    int64_t n, u64 seed, u64 offset, int mix, int flags, TkCount count, u32 *epoch, u32 play_groups, u32 fan,
     const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,
     uint8_t *__restrict__ done, uint16_t *__restrict__ trick, u64 *__restrict__ obs, uint8_t *__restrict__ hist,
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
@@ -1066,7 +1096,7 @@ __device__ __forceinline__ void step_role(
             }
         }
     };
-    launch_counted(epoch);                   // (issued BEFORE the count is waited for: its round trip runs beside the state's)
+    launch_counted<LAZY ? 0 : 1>(epoch);     // (issued BEFORE the count is waited for: its round trip runs beside the state's)
     g.cprev = 0;
     // ---- the card: krog's body (Klop.py:47-79, Navadna_igra.py:115-141), apply_step
     const bool play = valid && g.phase == TK_PHASE_PLAY;
@@ -1161,7 +1191,7 @@ __device__ __forceinline__ void step_role(
     // the launch's number is not even worked out
     const u32 total = push_count, late = lazy ? late_count : 0u;
     if ((total | late) == 0) return;
-    const u32 phase = launch_phase(count), par = phase & 1u;    // (`count` was requested before the state: it arrived with it)
+    const u32 phase = launch_phase<LAZY ? 0 : 1>(count, play_groups, fan), par = phase & 1u;    // (`count` was requested before the state: it arrived with it)
     if (total) {
         u64 *lst = rlist + ((int64_t)group * 2 + par) * TK_REFILL_CAP;
         if (active)
@@ -1180,6 +1210,9 @@ __device__ __forceinline__ void step_role(
     }
 }
 
+// (the library is built with kernel-argument preload — the first fourteen dwords arrive in scalar registers with the
+// dispatch instead of behind a scalar load: tarok_amd/_native.py.  Putting the state pointers first instead of the scalars
+// measured no better at 65,536 games and 3 % worse at 262,144: profiles/r04_ab_step.txt)
 #define TK_STEP_ARGS                                                                                                              \
     int64_t n, u64 seed, u64 offset, int mix, int flags, u32 play_groups, u32 *epoch, u32 fan,                                    \
         const uint8_t *__restrict__ action_in, uint8_t *__restrict__ action_out, int16_t *__restrict__ reward,                    \
@@ -1207,18 +1240,30 @@ __device__ __forceinline__ void step_role(
 template <bool RANDOM, bool LAZY>
 TK_KERNEL(TK_BLOCK, TK_STEP_VGPRS) __attribute__((amdgpu_waves_per_eu(TK_STEP_WAVES))) void k_step(TK_STEP_ARGS) {
     TK_VGPR_TOP(TK_STEP_VGPRS, TK_STEP_VTOP);
-    u32 count = launch_count(epoch);
-    // The refill workgroups are spread among the play workgroups — block q (fan + 1) works the lists of the `fan`
-    // play groups in the blocks after it off — so that their deals (instruction bound, ~2.7k per game) run UNDER the
-    // play workgroups' streaming instead of after it: at the end of the grid they were a 24 us tail of every
-    // launch that follows a trick's last card at 4 M games (profiles/r03_step_durations.txt).
+    TkCount count = launch_count<LAZY ? 0 : 1>(epoch, play_groups);
     __shared__ u32 finq[FINQ_WORDS][TK_BLOCK];
-    u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
-    if (r == 0)
-        refill_role<LAZY>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, LAZY, aux, rlist, rcount, elist);
-    else
-        step_role<RANDOM, LAZY>(blockIdx.x - q - 1, threadIdx.x, true, 255u, LAZY, n, seed, offset, mix, flags, count, epoch, action_in, action_out,
-                                reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
+    if (LAZY) {
+        // Kind 0 (launch_count): one workgroup per group and nothing else.  It plays the group's card, then works the
+        // group's own lists off: the per-launch list of the previous launch (only slots that dealt a game in place list
+        // anything there: empty in nearly every launch) and, in the first launch of a stretch, the previous stretch's
+        // list — every workgroup one pass of the deal on ~100-200 lanes.  (Round 3 had 256 refill workgroups beside the
+        // 256 step workgroups at 65,536 games; with nothing to do in fifteen launches of sixteen they still cost every
+        // launch ~0.9 us of dispatch and wave slots: profiles/r04_ab_step.txt.)
+        step_role<RANDOM, true>(blockIdx.x, threadIdx.x, true, 255u, true, n, seed, offset, mix, flags, count, epoch, play_groups, fan, action_in,
+                                action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
+        refill_role<true>(blockIdx.x, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, true, aux, rlist, rcount, elist);
+    } else {
+        // Kind 1, the streaming batches: the refill workgroups are spread among the play workgroups — block q (fan + 1)
+        // works the lists of the `fan` play groups in the blocks after it off — so that their deals (instruction bound,
+        // ~2.7k per game) run UNDER the play workgroups' streaming instead of after it: at the end of the grid they were a
+        // 24 us tail of every launch that follows a trick's last card at 4 M games (profiles/r03_step_durations.txt).
+        u32 q = blockIdx.x / (fan + 1), r = blockIdx.x % (fan + 1);
+        if (r == 0)
+            refill_role<false>(q, threadIdx.x, TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, elist);
+        else
+            step_role<RANDOM, false>(blockIdx.x - q - 1, threadIdx.x, true, 255u, false, n, seed, offset, mix, flags, count, epoch, play_groups, fan,
+                                     action_in, action_out, reward, done, trick, obs, hist, s01, s23, aux, cnt, gkey, rlist, rcount, elist, finq);
+    }
 }
 
 // Whole games in registers: deal, setup, Bot exchange, random play to the end.
@@ -2104,7 +2149,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) TK_VGPR_BUDGET(256) void k_policy_
     ulonglong2 *__restrict__ s01, ulonglong2 *__restrict__ s23, Aux *aux, Counters *__restrict__ cnt,
     u64 *__restrict__ gkey, u64 *rlist, u32 *rcount) {
     TK_VGPR_TOP(256, 255);
-    u32 count = launch_count(epoch);          // (in flight under the policy's first loads)
+    TkCount count = launch_count<1>(epoch, play_groups);          // (in flight under the policy's first loads)
     if (blockIdx.x >= play_groups) {
         refill_role<false>(blockIdx.x - play_groups, threadIdx.x, 2 * TK_BLOCK, seed, offset, mix, play_groups, count, epoch, fan, false, aux, rlist, rcount, nullptr);
         return;
@@ -2116,7 +2161,7 @@ __global__ __launch_bounds__(2 * TK_BLOCK, 2) TK_VGPR_BUDGET(256) void k_policy_
     __syncthreads();                          // (the policy's LDS is free from here on: the step's scoring list goes there)
     u32 tid = threadIdx.x;
     step_role<false, false>(blockIdx.x, tid & (TK_BLOCK - 1), tid < TK_BLOCK, act_s[tid & (TK_BLOCK - 1)], false, n, seed, offset, mix, flags,
-                           count, epoch, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr,
+                           count, epoch, play_groups, fan, nullptr, nullptr, reward, done, trick, obs_out, hist, s01, s23, aux, cnt, gkey, rlist, rcount, nullptr,
                            reinterpret_cast<u32 (*)[TK_BLOCK]>(lds));
 }
 
@@ -2405,8 +2450,8 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     if (r == hipSuccess) r = hipMalloc((void **)&e->rcount, TK_RC(groups, 0) * sizeof(u32));
     if (r == hipSuccess) r = hipMalloc((void **)&e->elist, groups * 2 * TK_BULK_CAP * sizeof(u64));
     if (r == hipSuccess) r = hipMalloc((void **)&e->adam_sumsq, 1024 * sizeof(float));
-    if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 32 * TK_EPOCH_SHARDS * sizeof(u32));
-    if (r == hipSuccess) r = hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32));
+    if (r == hipSuccess) r = hipMalloc((void **)&e->epoch, 2 * TK_EPOCH_WORDS * sizeof(u32));
+    if (r == hipSuccess) r = hipMemset(e->epoch, 0, 2 * TK_EPOCH_WORDS * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->rcount, 0, TK_RC(groups, 0) * sizeof(u32));
     if (r == hipSuccess) r = hipMemset(e->s01, 0, (size_t)n_games * sizeof(ulonglong2));
     if (r == hipSuccess) r = hipMemset(e->s23, 0, (size_t)n_games * sizeof(ulonglong2));
@@ -2453,7 +2498,7 @@ int tarok_set_option(tarok_env *e, int option, int value) {
             // so) until its slot reaches it, deals that game in place and lists all its lines again.
             HIPCHK(hipSetDevice(e->device));
             HIPCHK(hipDeviceSynchronize());
-            HIPCHK(hipMemset(e->epoch, 0, 32 * TK_EPOCH_SHARDS * sizeof(u32)));
+            HIPCHK(hipMemset(e->epoch, 0, 2 * TK_EPOCH_WORDS * sizeof(u32)));
             HIPCHK(hipMemset(e->rcount, 0, TK_RC((e->n + TK_BLOCK - 1) / TK_BLOCK, 0) * sizeof(u32)));
         }
         e->refill_fan = (uint32_t)value;
@@ -2524,6 +2569,7 @@ static inline void launch_play(tarok_env *e, bool random, int cards, int64_t str
     u32 fan = e->refill_fan;
     dim3 grid(groups + (groups + fan - 1) / fan);
     e->launched = 1;
+    if (cards == 1 && e->lazy_refill) grid = dim3(groups);     // kind 0 (launch_count): the step workgroups work their own lists off
     if (cards == 1) {
 #define TK_LAUNCH_STEP(R, Z)                                                                                             \
     hipLaunchKernelGGL((k_step<R, Z>), grid, dim3(TK_BLOCK), 0, s, e->n, e->seed, e->offset, e->mix, flags, groups, e->epoch, \

@@ -66,3 +66,20 @@ def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def gather_over_ranks(value):
+    """[value of rank 0, ..., value of rank W-1] on every rank (one float per rank: per-rank timings of a bench line)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    w, r = dist.get_world_size(), dist.get_rank()
+    return sum_over_ranks([float(value) if k == r else 0.0 for k in range(w)])
+
+
+def group_info():
+    """{"world_size", "backend"} of the process group the collectives above run on (1 / None without one)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return {"world_size": dist.get_world_size(), "backend": dist.get_backend()}
+    return {"world_size": 1, "backend": None}

@@ -194,3 +194,70 @@ def test_profile_provenance_is_flagged_stale(tmp_path, monkeypatch):
     assert prov["stale"] is True and prov["measured_on_kernel_src_sha"] == "abc"
     assert bench.load_profile("missing.json", "abc") == (None, {"source": None})
     assert len(bench.kernel_src_sha()) == 16
+
+
+def _two_rank_bench_worker(rank, world_size, port, q):
+    """One gloo rank of `bench.py --gpus 2` on the fake env (spawned: the fakes are installed by hand)."""
+    import os
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), TAROK_BENCH_ONE_GPU="1")
+    import io, contextlib, time
+    import tarok_amd
+    FakeEnv.instances.clear()
+    tarok_amd.build = lambda *a, **k: None
+    tarok_amd.TarokVecEnv = FakeEnv
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: object()
+    torch.cuda.Event = FakeEvent
+    fake_sp = types.ModuleType("tarok_amd.selfplay")
+
+    class SelfPlay:
+        def __init__(self, *a, **k):
+            raise RuntimeError("no GPU in this test")
+    fake_sp.SelfPlay = SelfPlay
+    sys.modules["tarok_amd.selfplay"] = fake_sp
+    tarok_amd.selfplay = fake_sp
+    # rank 1 is the slow one: its launches "take" 30 ms longer; the group's barrier costs what it costs
+    real_run = FakeEnv.run_random
+
+    def slow_run(self, *a, **k):
+        real_run(self, *a, **k)
+        if rank == 1:
+            time.sleep(0.03)
+    FakeEnv.run_random = slow_run
+    sys.argv = ["bench.py", "--no-cpu-baseline", "--no-extras", "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    if rank == 0:
+        q.put(buf.getvalue())
+
+
+def test_two_rank_bench_line_times_each_rank_before_the_trailing_barrier():
+    """`bench.py --gpus 2` as two gloo ranks on the fake env: ONE line from rank 0; value = all ranks' steps over the
+    MAX over ranks of each rank's own wall time (clock stopped before the trailing barrier), per-rank wall and HIP-event
+    times and the process group on the line."""
+    import torch.multiprocessing as mp
+    from tests.test_sharding_gloo import _free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    tr = line["timed_region"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert tr["process_group"] == {"world_size": 2, "backend": "gloo"} and tr["rccl_ranks_seen"] == 0
+    assert len(tr["wall_ms_per_rank"]) == 2 and len(tr["hip_event_ms_per_rank"]) == 2
+    assert tr["wall_ms_per_rank"][1] >= 30.0 > tr["wall_ms_per_rank"][0]               # the slow rank's own time, not shared
+    assert tr["wall_ms_max_over_ranks"] == pytest.approx(max(tr["wall_ms_per_rank"]))
+    steps = 2 * 65536 * line["lock_steps_timed"]
+    assert line["value"] == pytest.approx(steps / (tr["wall_ms_max_over_ranks"] * 1e-3))

@@ -8,6 +8,6 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/ab
 for v in "a_block256:256" "b_block512:512" "c_block1024:1024"; do
   name=${v%%:*}; blk=${v##*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I include -DTK_BLOCK=$blk -o tools/ab/$name.so tarok_amd/csrc/tarok_env.hip
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-kernarg-preload-count=16 -I include -DTK_BLOCK=$blk -o tools/ab/$name.so tarok_amd/csrc/tarok_env.hip
 done
 ls -la tools/ab
