@@ -61,7 +61,8 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_STEP = 54
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s HBM3E
-PROFILE_TAG = "r03"             # profiles/<tag>_* are the files read below
+PROFILE_TAG = "r04"             # profiles/<tag>_* are the files read below
+LAUNCH_BOUNDARY_US = 1.45       # a dependent kernel boundary on MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 SEEDS = (0, 1, 2)               # SURVEY 8d / BASELINE.md: the repeats rotate these seeds
 STREAM_GAMES = 1 << 22          # the step API's streaming leg
 SIDE_LOCK_STEPS_CAP = 7680      # side legs: at most this many lock-steps per timed region
@@ -410,10 +411,16 @@ def main():
                                  "note": "tarok_policy_random + tarok_step per lock-step (2 launches): what an external policy drives"}
         if rank == 0:
             ach = ALGO_BYTES_PER_STEP * n / (us0 * 1e-6) / 1e9
-            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false, true> (tarok_step; at this size the instantiation with the bulk deals) behind k_policy (tarok_policy_random)",
+            out["roofline_step_api"] = {"bound": "hbm", "kernel": "k_step<false, true> (tarok_step; at this size the instantiation without refill workgroups: every step workgroup works its own lists off, bulk deals every 32nd launch) behind k_policy (tarok_policy_random)",
                                         "accounting": "algorithmic 54 B/step (SURVEY 8d) x %d games per lock-step" % n,
                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                         "us_per_lock_step": us0, "traffic": None,
+                                        # what actually bounds a lock-step at this size: two dependent launches
+                                        "latency_floor": {"dependent_boundaries_per_lock_step": 2, "us_per_boundary": LAUNCH_BOUNDARY_US,
+                                                          "floor_us": 2 * LAUNCH_BOUNDARY_US, "frac": 2 * LAUNCH_BOUNDARY_US / us0,
+                                                          "note": "MI355X_MICROARCH.md: ~1.45 us per dependent kernel boundary; a lock-step "
+                                                                  "of the external-policy path is policy launch -> step launch, each "
+                                                                  "waiting for the other's output: frac = floor / measured"},
                                         "note": "wall time of the timed region / lock-steps: both launches and their gaps are "
                                                 "charged to the step; at %d games (state cache resident, one wave per SIMD) a "
                                                 "launch is latency bound — see profiles/ for the N sweep of this path" % n}

@@ -43,4 +43,5 @@ find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.cs
 find $OUT/stats_all -name "*kernel_stats.csv" -exec cp {} $OUT/bench_all_modes_kernel_stats.csv \;
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +4M -delete
+bash tools/leg_stats.sh $TAG/legs > /dev/null 2>&1; cp gpurun_out/$TAG/legs/leg_*_kernel_stats.csv gpurun_out/$TAG/legs/leg_times.txt $OUT/ 2>/dev/null
 echo ALL DONE

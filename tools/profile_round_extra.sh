@@ -14,9 +14,9 @@ for m in random two; do
   rm -rf $OUT/dur_$m
 done
 # 65,536 games: the one-card step deals in bulk every sixteenth launch there (period 16: launch number mod 16, 0 = the bulk launch)
-rocprofv3 --kernel-trace --output-format csv -d $OUT/dur_small -- python3 tools/step_ledger.py 65536 two d 0 1 176 > $OUT/dur_small.log 2>&1
-echo "65,536 games, by launch number mod 16:" >> $OUT/step_durations_final.txt
-python3 tools/step_durations.py $OUT/dur_small 65536 16 >> $OUT/step_durations_final.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/dur_small -- python3 tools/step_ledger.py 65536 two d 0 1 224 > $OUT/dur_small.log 2>&1
+echo "65,536 games, by launch number mod 32:" >> $OUT/step_durations_final.txt
+python3 tools/step_durations.py $OUT/dur_small 65536 32 >> $OUT/step_durations_final.txt
 rm -rf $OUT/dur_small
 echo "durations done"
 for N in 4194304 65536; do bash tools/step_sq.sh $N two ${TAG}x/sq > /dev/null 2>&1; done
