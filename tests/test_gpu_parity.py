@@ -1127,6 +1127,48 @@ def test_launch_tuning_changed_in_the_middle_of_a_mixed_run(T, O, S):
     env.close()
 
 
+@pytest.mark.parametrize("n,lazy", [(65536, None), (20000, None), (65536, 0)])
+def test_callers_own_graph_of_the_step_api_replayed_between_other_launches(T, O, S, n, lazy):
+    """What an external policy's training loop does: ITS OWN torch.cuda.graph around `policy -> step` (seven lock-steps: a
+    length that divides nothing the kernels count in), replayed dozens of times with eager steps, the library's graphs and
+    multi-card launches in between.  The step kernels take their launch number from device-side counters (two kinds of
+    launch, §3.3), so a replayed graph — fixed arguments — lands on the right refill lists wherever it is replayed."""
+    import torch
+    seed = 5
+    env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
+    obs = env.reset()
+    steps = 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up on the capture stream (allocations outside the capture)
+        for _ in range(3):
+            env.policy_random(); env.step(env.action, auto_reset=True); steps += 1
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(7):
+            env.policy_random(); env.step(env.action, auto_reset=True)
+    steps += 7                                          # (capture does not run the launches; the first replay below does)
+    rnd = np.random.RandomState(3)
+    g.replay()
+    for it in range(60):
+        kind = rnd.randint(0, 5)
+        if kind <= 1:
+            g.replay(); steps += 7
+        elif kind == 2:
+            k = int(rnd.randint(1, 9))
+            for _ in range(k):
+                env.policy_random(); env.step(env.action, auto_reset=True)
+            steps += k
+        elif kind == 3:
+            env.run_random(32, cards_per_launch=1, graph_chunk=16, auto_reset=True); steps += 32
+        else:
+            k = int(rnd.choice([4, 12, 64])); env.krog_random(k, auto_reset=True); steps += k
+    torch.cuda.synchronize()
+    _assert_equals_oracle(env, O, S, seed, n, steps)
+    env.close()
+
+
 @pytest.mark.parametrize("n,lazy", [(65536, None), (65536, 0), (20000, None), (1 << 20, None)])
 def test_refill_role_of_every_step_kernel_deals_its_lists_right(T, S, n, lazy):
     """tarok_debug_refill_selftest: the refill role as k_step (Bot policy / cards given, with and without the bulk-deal
