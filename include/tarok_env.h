@@ -105,7 +105,7 @@ int64_t tarok_num_games(const tarok_env *env);
  *                               dropped are dealt by their slots when they get there) — do it between phases, not per step,
  *                               and not while a caller's graph holding this env's step launches is to be replayed
  *   TAROK_OPT_LAZY_REFILL  0/1  tarok_step / tarok_step_random: the next-game lines their slots empty are dealt in bulk
- *                               every sixteenth launch instead of in the launch after (default: on below 2^20 games);
+ *                               every thirty-second launch instead of in the launch after (default: on below 2^20 games);
  *                               free to change between any two launches */
 #define TAROK_OPT_REFILL_FAN 2
 #define TAROK_OPT_LAZY_REFILL 3

@@ -17,10 +17,12 @@
 // in one) practically never wait for a deal (with seven, round 1, 64 cards were the limit: a slot that
 // finishes more games within two launches than it has lines deals in place, and the launch is its
 // slowest wave).  Lists are double-buffered by launch parity — the low bit of the launch number, which is kept
-// modulo 32 in DEVICE memory as a count of started workgroups that every step launch advances by its grid size
-// (launch_count / launch_counted / launch_phase), so eager launches and replays of captured graphs (the library's
-// own or a caller's, e.g. torch.cuda.graph) mix freely and in any number.  The one-card step of small batches does
-// not deal the lines it empties in the next launch at all but collects them for a bulk deal every sixteenth launch
+// modulo 64 in DEVICE memory as counts of started workgroups that every step launch advances by its grid size
+// (launch_count / launch_counted / launch_phase; two kinds of launch with two grid sizes, each counted on its own,
+// the launch number is the sum), so eager launches and replays of captured graphs (the library's own or a caller's,
+// e.g. torch.cuda.graph) mix freely and in any number.  The one-card step of small batches (kind 0) has no extra
+// workgroups: every step workgroup works its own group's lists off after playing its card, and it does not deal the
+// lines it empties in the next launch at all but collects them for a bulk deal every thirty-second launch
 // (refill_role<true>, TAROK_OPT_LAZY_REFILL).  A line is valid iff its episode tag matches
 // and it is not being re-dealt right now (`cprev` in the slot's state), and a slot that ever runs
 // out of usable lines just deals the game itself, wave-cooperatively (ballot/readlane), same result.
@@ -450,7 +452,7 @@ template <int KIND> __device__ __forceinline__ void launch_counted(u32 *epoch) {
 // its trick and games end on a trick's 4th card, so they would all be dealt in the launch after it, whose refill
 // workgroups (a wave alone issues an instruction every ~4.5 cycles, a deal is 2.7k of them) outlast the step
 // workgroups: 9.9 us against 4.3 at 65,536 games, 79 against 44 at 4 M (profiles/r03_step_durations.txt,
-// r03_ab_step.txt (e)).  A slot has fourteen lines and takes at most four in sixteen launches, so step_role collects
+// r03_ab_step.txt (e)).  A slot has fourteen lines and takes at most eight in thirty-two launches, so step_role collects
 // those entries in a second pair of lists per workgroup, switched every TK_BULK_EVERY launches, and the first launch
 // of each such stretch works the previous stretch's list off here, on dense lanes, in one go.  A line waits for its
 // deal at most TK_BULK_EVERY launches and is not needed again before thirteen more games of its slot have
@@ -2434,7 +2436,7 @@ int tarok_create(tarok_env **out, int device, int64_t n_games, uint64_t game_off
     e->refill_fan = n_games >= (1 << 20) ? TK_REFILL_FAN : (n_games >= (1 << 18) ? 4 : 1);
     // Bulk deals where a launch is a handful of workgroups per CU and its refill workgroups' deals are its tail (65,536
     // games: -8 % per lock-step, 262,144: -7 %); where the batch streams the deals' instructions add to the launch
-    // wherever they run, and sixteen launches' worth at once cost what they cost one trick at a time (profiles/r03_ab_step.txt (e))
+    // wherever they run, and a whole stretch of launches' worth at once cost what they cost one trick at a time (profiles/r03_ab_step.txt (e))
     e->lazy_refill = n_games < (1 << 20) ? 1 : 0;
     size_t stale_bytes = (size_t)((n_games + TK_PF_SLOTS - 1) / TK_PF_SLOTS) * TK_PF_SLOTS * sizeof(uint16_t);
     hipError_t r = hipMalloc((void **)&e->s01, (size_t)n_games * sizeof(ulonglong2));

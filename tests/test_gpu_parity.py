@@ -298,7 +298,7 @@ def test_auto_reset_run_vs_oracle_full_size(T, O, S):
     # cards per launch: 0 = policy + step kernels, 1 = fused one-card kernel, >= 2 = tarok_krog_random
     # fan: refill lists per refill workgroup (tarok_set_option; None = the default for the size, 1)
     # (the bench's own launch shape, 128 cards x 65,536 games, is test_bench_launch_shape_vs_oracle)
-    # lazy: the one-card step's emptied lines dealt in bulk every sixteenth launch (tarok_set_option; the default below 2^20
+    # lazy: the one-card step's emptied lines dealt in bulk every thirty-second launch (tarok_set_option; the default below 2^20
     # games) or in the launch after (0)
     for cards, chunk, pf, fan, *lazy in [(0, 48, 4, None), (1, 0, 0, None), (1, 64, 16, None), (0, 0, 2, None),
                                   (0, 48, 0, 8), (1, 64, 0, 3), (1, 0, 16, 8), (0, 96, 0, 4),
@@ -325,7 +325,7 @@ def test_step_api_streaming_size_vs_oracle(T, O, S):
     canonical state and observation word."""
     n, seed, steps = 1 << 20, 9, 96
     ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
-    for cards, lazy in ((0, None), (1, None), (1, 1)):         # (lazy: bulk deals every sixteenth launch — off by default at this size)
+    for cards, lazy in ((0, None), (1, None), (1, 1)):         # (lazy: bulk deals every thirty-second launch — off by default at this size)
         env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
         env.reset()
         env.run_random(steps, cards_per_launch=cards, graph_chunk=48, auto_reset=True)
@@ -997,7 +997,7 @@ def test_four_million_games_headline_mode_is_deterministic_and_shards_agree(T, S
 def test_mixed_launch_kinds_keep_the_refill_pipeline_consistent(T, O, S, lazy):
     """Graph replays, eager one-card steps, tricks, the two-kernel path and a mid-run reset, mixed
     (odd launch counts between graphs exercise the parity flush): still the oracle's games.  lazy (the default at
-    this size): the one-card launches collect the lines they empty for a bulk deal every sixteenth launch; launches of
+    this size): the one-card launches collect the lines they empty for a bulk deal every thirty-second launch; launches of
     the multi-card kernel in between drop what was collected."""
     n, seed = 20000, 41
     env = T.TarokVecEnv(n, seed=seed, mix=S.MIX_ALL, lazy_refill=lazy)
