@@ -26,7 +26,7 @@
             if (amt == 37) amt = 38;                                                                                   \
             unsigned long long r;                                                                                      \
             asm volatile("v_mov_b32 v0, 37\n\tv_mov_b32 v" STR(AMT) ", %1\n\ts_nop 4\n\t" INSN "\n\ts_nop 1"                    \
-                         : "=v"(r) : "v"(amt), "v"(0x8123456789ABCDEFULL) : "v0", "v" STR(TOP), "v" STR(AMT));         \
+                         : "=v"(r) : "v"(amt), "v"(0x8123456789ABCDEFULL) : "v0", "v" STR(TOP), "v" STR(AMT), "s10", "s11"); \
             if (r != (unsigned long long)(EXPECT)) { wrong++; if (r == (unsigned long long)(EXPECT_V0)) wrong_v0++; }  \
             for (uint32_t s = 0; s < spin; s++) asm volatile("s_nop 7");                                               \
         }                                                                                                              \
@@ -54,6 +54,12 @@ PROBE_KERNEL(k_last_127, 127, 127)
 PROBE_KERNEL(k_ctrl_127, 127, 126)
 PROBE_KERNEL_OP(k_lshr_103, 103, 103, "v_lshrrev_b64 %0, v103, %2", (0x8123456789ABCDEFULL >> amt), (0x8123456789ABCDEFULL >> 37))
 PROBE_KERNEL_OP(k_ashr_103, 103, 103, "v_ashrrev_i64 %0, v103, %2", ((long long)0x8123456789ABCDEFULL >> amt), ((long long)0x8123456789ABCDEFULL >> 37))
+// other instructions that mix a 32-bit VGPR operand with 64-bit ones (is the erratum wider than LLVM's list of three?):
+//   v_mad_u64_u32 d, a32, b32, c64 with a32 in the last register; v_cvt_f64_u32 d64, a32; v_ldexp_f64 d64, a64, e32;
+//   v_lshl_add_u64 with its 64-bit addend ENDING in the last register (a genuine pair: control)
+PROBE_KERNEL_OP(k_mad64_103, 103, 103, "v_mad_u64_u32 %0, s[10:11], v103, 3, %2", (0x8123456789ABCDEFULL + 3ULL * amt), (0x8123456789ABCDEFULL + 3ULL * 37))
+PROBE_KERNEL_OP(k_cvt64_103, 103, 103, "v_cvt_f64_u32 %0, v103", __double_as_longlong((double)amt), __double_as_longlong(37.0))
+PROBE_KERNEL_OP(k_ldexp_103, 103, 103, "v_ldexp_f64 %0, 1.0, v103", __double_as_longlong(ldexp(1.0, (int)amt)), __double_as_longlong(ldexp(1.0, 37)))
 
 typedef void (*kern_t)(uint32_t *, uint32_t, uint32_t);
 
@@ -64,6 +70,8 @@ int main() {
         {"amount in v103 = last of 104", k_last_103}, {"amount in v102 (control)", k_ctrl_103}, {"amount in v95  (index & 7 == 7, not last)", k_mid_103},
         {"amount in v127 = last of 128", k_last_127}, {"amount in v126 (control)", k_ctrl_127},
         {"v_lshrrev_b64, amount in v103 = last of 104", k_lshr_103}, {"v_ashrrev_i64, amount in v103 = last of 104", k_ashr_103},
+        {"v_mad_u64_u32, 32-bit factor in v103 = last of 104", k_mad64_103}, {"v_cvt_f64_u32, source in v103 = last of 104", k_cvt64_103},
+        {"v_ldexp_f64, exponent in v103 = last of 104", k_ldexp_103},
     };
     const int blocks = 2048, threads = 256, waves = blocks * threads / 64;
     uint32_t *d;
