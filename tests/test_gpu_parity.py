@@ -1083,8 +1083,8 @@ def _mixed_segments(env, rnd, target, between=None):
     return steps
 
 
-def _assert_equals_oracle(env, O, S, seed, n, steps):
-    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL, steps, threads=16)
+def _assert_equals_oracle(env, O, S, seed, n, steps, mix=None):
+    ref = O.run_autoreset(seed, 0, n, S.MIX_ALL if mix is None else mix, steps, threads=16)
     ep, ss = env.counters()
     assert (ep == ref["episode"]).all() and (ss == ref["score_sum"]).all()
     assert (env.state() == ref["lanes"]).all()
@@ -1102,6 +1102,21 @@ def test_mixed_launch_soak_sequences_that_caught_the_refill_bug(T, O, S, lazy, t
     env.reset()
     steps = _mixed_segments(env, np.random.RandomState(n % 1000 + target), target)
     _assert_equals_oracle(env, O, S, seed, n, steps)
+    env.close()
+
+
+@pytest.mark.parametrize("mixname,lazy", [("berac", None), ("berac", 0), ("klop", None), ("bot", None)])
+def test_mixed_launch_kinds_on_batches_of_one_contract_family(T, O, S, mixname, lazy):
+    """The mixed sequence on batches whose games end in step with each other or as fast as the rules allow: all Berac (games of
+    4 .. 48 cards: a slot can end eight games in a stretch of 32 one-card launches — the stretch lists' capacity — and
+    several per multi-card launch), all Klop (every game 48 cards: all 32,768 slots end on the same card, one stretch list
+    entry per slot at once) and contracts from the on-device bidding; 32,768 games, ~2,000 lock-steps, vs the oracle."""
+    n, seed, target = 32768, 23, 2000
+    mix = {"berac": S.MIX_FIXED + 7, "klop": S.MIX_FIXED + 0, "bot": 2}[mixname]
+    env = T.TarokVecEnv(n, seed=seed, mix=mix, lazy_refill=lazy)
+    env.reset()
+    steps = _mixed_segments(env, np.random.RandomState(101), target)
+    _assert_equals_oracle(env, O, S, seed, n, steps, mix=mix)
     env.close()
 
 
