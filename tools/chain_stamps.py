@@ -17,6 +17,13 @@ sp.update_fused(buf, epochs=1, minibatches=8)
 torch.cuda.synchronize()
 _native.check(env.L.tarok_debug_stamps(env._h, None))
 s = st.cpu().numpy().astype(np.int64)
+if len(sys.argv) > 1 and sys.argv[1] == "fine":      # a library built with -DLN_FINE_STAMPS (TAROK_LIB)
+    d = np.diff(s[:, :8], axis=1)
+    print("k_learn_chain, layers 1-2 in detail (wave 0's clock; two workgroups share the CU), shader cycles (median | p10 | p90):")
+    for k, nm in enumerate(["gather+expand", "layer 1 GEMM", "layer 1 barrier + epilogue + barrier", "layer 1 tile store (issue)", "layer 2 GEMM",
+                            "layer 2 barrier + epilogue + barrier", "layer 2 tile store (issue)"]):
+        print("  %-38s %8d | %8d | %8d" % (nm, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
+    sys.exit(0)
 d = np.diff(s[:, :7], axis=1)
 names = ["gather+expand", "layer 1", "layer 2", "layer 3 + loss", "dH2", "dH1"]
 print("k_learn_chain, last minibatch of an update (4,096 workgroups of 96 samples), shader cycles per phase (median | p10 | p90):")
