@@ -522,9 +522,10 @@ def main():
             from tarok_amd import selfplay
             env.reset(episode=0)
             sp = selfplay.SelfPlay(env, hidden=256, seed=0)
-            sp.iterate(T=48, epochs=1, minibatches=8)                 # graph capture, buffers, first launches: untimed
-            its = [sp.iterate(T=48, epochs=1, minibatches=8) for _ in range(3)]
-            st = sorted(its, key=lambda q: q["rollout_s"] + q["update_s"])[1]     # the median iteration of three
+            for _ in range(3):                                        # graph capture, buffers, first launches, clocks: untimed
+                sp.iterate(T=48, epochs=1, minibatches=8)             # (an iteration is 5-6 ms: the second and third still speed up)
+            its = [sp.iterate(T=48, epochs=1, minibatches=8) for _ in range(7)]
+            st = sorted(its, key=lambda q: q["rollout_s"] + q["update_s"])[3]     # the median iteration of seven
             tro = sharding.max_over_ranks([st["rollout_s"], st["update_s"]])
             out["selfplay_ppo"] = {"iteration_env_steps_per_s": n * 48 * world_size / (tro[0] + tro[1]),
                                    "rollout_env_steps_per_s": n * 48 * world_size / tro[0], "rollout_us_per_lock_step": tro[0] / 48 * 1e6,
@@ -533,7 +534,7 @@ def main():
                                    "learner": "fused (tarok_learn_*)" if getattr(sp, "fused_learner", False) else "torch",
                                    "iterations_ms": [(q["rollout_s"] + q["update_s"]) * 1e3 for q in its],
                                    "note": "iteration = one rollout of 48 lock-steps + one update over its %d samples (1 epoch, 8 "
-                                           "minibatches): the end-to-end figure (the median of three iterations after an untimed first one).  Rollout: per lock-step one tarok_policy_step launch "
+                                           "minibatches): the end-to-end figure (the median of seven iterations after three untimed ones).  Rollout: per lock-step one tarok_policy_step launch "
                                            "(features -> MLP -> masked sample -> env step), graph replayed.  Update: returns kernel; per "
                                            "minibatch forward + loss + backward chain in one MFMA kernel, the three weight gradients as "
                                            "one split-K launch, one flat gradient all-reduce, clip + Adam in one launch" % (n * 48)}
