@@ -364,6 +364,8 @@ int tarok_targets_ref(tarok_env *env, int T, const uint64_t *obs_before, const u
 #define TAROK_MLP_B3 147968
 #define TAROK_MLP_PARAMS 148032
 #define TAROK_LEARN_PAD 256 /* padding rows of the activation arrays of tarok_learn_chain / tarok_learn_dw */
+#define TAROK_LEARN_MAX_BATCH 4194048 /* samples per minibatch of tarok_learn_dw (its arrays are addressed through 32-bit
+                                       * byte offsets: (B + TAROK_LEARN_PAD) * 512 < 2^31); larger: TAROK_EINVAL */
 
 /* Returns of a rollout of T lock-steps (rows [T,N] as written by tarok_policy_step): every card is credited with
  * its seat's final score of the game it belongs to, times reward_scale.
@@ -391,7 +393,8 @@ int tarok_learn_chain(tarok_env *env, int64_t B, const uint64_t *feature_words, 
                       float *running, void *stream);
 
 /* The weight and bias gradients of that minibatch: grad_out [TAROK_MLP_PARAMS] f32 = terms[3] * (dH^T H per layer,
- * column sums of dH), in the flat parameter order.  workspace: tarok_learn_workspace_bytes(env) bytes. */
+ * column sums of dH), in the flat parameter order.  workspace: tarok_learn_workspace_bytes(env) bytes.
+ * B <= TAROK_LEARN_MAX_BATCH. */
 int64_t tarok_learn_workspace_bytes(tarok_env *env);
 int tarok_learn_dw(tarok_env *env, int64_t B, const uint64_t *Xw, const void *H1,
                    const void *H2, const void *dOut, const void *dH2, const void *dH1, const float *terms,

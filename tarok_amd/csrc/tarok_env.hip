@@ -2967,6 +2967,7 @@ int tarok_learn_dw(tarok_env *e, int64_t B, const uint64_t *Xw, const void *H1, 
                    const void *dOut, const void *dH2, const void *dH1, const float *terms, void *workspace, float *grad_out,
                    void *stream) {
     if (!e || B < 1 || !Xw || !H1 || !H2 || !dOut || !dH2 || !dH1 || !terms || !workspace || !grad_out) return TAROK_EINVAL;
+    if (B > TAROK_LEARN_MAX_BATCH) return TAROK_EINVAL;       // (k_learn_dw addresses its arrays through 32-bit buffer offsets: 512 B rows)
     HIPCHK(hipSetDevice(e->device));
     u32 c2, c1, c3;
     learn_chunks(e, c2, c1, c3);

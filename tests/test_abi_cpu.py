@@ -73,6 +73,7 @@ def test_round3_entry_points_reject_bad_arguments_without_a_gpu(libpath):
     assert L.tarok_targets_ref(None, 48, z, z, z, z, z, z, 0.1, z, z, z) == -1
     assert L.tarok_learn_returns(None, 48, z, z, z, z, z, z, 1.0, z, z, z, z) == -1
     assert L.tarok_learn_dw(None, 128, z, z, z, z, z, z, z, z, z, z) == -1
+    assert L.tarok_learn_dw(None, 1 << 23, z, z, z, z, z, z, z, z, z, z) == -1         # (also past TAROK_LEARN_MAX_BATCH)
     assert L.tarok_learn_adam(None, z, z, z, z, z, 1e-3, 0.9, 0.999, 1e-8, 1.0, z, z, z, z, z, z, 1, z) == -1
 
 
