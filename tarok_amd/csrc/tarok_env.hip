@@ -1856,6 +1856,19 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define PM_M 128
+// the eight bits of a byte as eight bf16 0.0 / 1.0 (16 bytes): bit k of b lands on bit 8k of (b * 0x204081) (copies of b at shifts
+// 0, 7, 14, 21), a byte permute puts two of those bytes into the halves of a word, times 0x3F80 — 13 instructions per byte where
+// a select per bit takes 28 (the learner's kernels expand their feature words with it too)
+__device__ __forceinline__ uint4 tk_expand_byte(u32 b) {
+    u32 lo = __umul24(b & 15u, 0x204081u) & 0x01010101u;        // byte k = bit k
+    u32 hi = __umul24(b >> 4, 0x204081u) & 0x01010101u;         // byte k = bit 4 + k
+    uint4 v;
+    v.x = __umul24(__builtin_amdgcn_perm(0u, lo, 0x0C010C00u), 0x3F80u);   // bytes {lo.0, 0, lo.1, 0}
+    v.y = __umul24(__builtin_amdgcn_perm(0u, lo, 0x0C030C02u), 0x3F80u);
+    v.z = __umul24(__builtin_amdgcn_perm(0u, hi, 0x0C010C00u), 0x3F80u);
+    v.w = __umul24(__builtin_amdgcn_perm(0u, hi, 0x0C030C02u), 0x3F80u);
+    return v;
+}
 #define PM_LD 264
 #define PM_LL 68             // f32 logits row stride (272 B: float4 stores stay aligned)
 
@@ -1986,12 +1999,7 @@ __device__ __forceinline__ void policy_body(
         for (int j = 0; j < 16; j++) {
             u32 chunk = 2 * j + par;                       // byte `chunk` of the row = byte (2j + par) & 3 of word j / 2
             u32 byte = (wd[j >> 1] >> (8 * ((2 * (j & 1)) + par))) & 255u;
-            uint4 v;
-            v.x = ((byte & 1) ? 0x3F80u : 0u) | ((byte & 2) ? 0x3F800000u : 0u);
-            v.y = ((byte & 4) ? 0x3F80u : 0u) | ((byte & 8) ? 0x3F800000u : 0u);
-            v.z = ((byte & 16) ? 0x3F80u : 0u) | ((byte & 32) ? 0x3F800000u : 0u);
-            v.w = ((byte & 64) ? 0x3F80u : 0u) | ((byte & 128) ? 0x3F800000u : 0u);
-            *reinterpret_cast<uint4 *>(X + gme * PM_LD + 8 * chunk) = v;
+            *reinterpret_cast<uint4 *>(X + gme * PM_LD + 8 * chunk) = tk_expand_byte(byte);
         }
     }
     if (features_out) {                                    // optional global copy: full 512-byte rows per 32 lanes
