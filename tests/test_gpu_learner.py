@@ -252,3 +252,23 @@ def test_selfplay_fused_learner_matches_the_torch_update(T):
     assert st["env_errors"] == 0 and np.isfinite(st["loss"]) and st["iteration_steps_per_s"] > 0
     for e in envs:
         e.close()
+
+
+def test_fused_update_is_reproducible_bit_for_bit(T):
+    """Two learners from the same seed on two envs: rollouts, every minibatch's gradient (split-K partial sums added in a
+    fixed order, no atomics), Adam and the weight copies give the SAME bits after three iterations — the update has no
+    run-to-run freedom (which is also why its tile-to-workgroup assignment is static: profiles/r04_learner_steps.txt (6))."""
+    import torch
+    from tarok_amd import selfplay as SP
+    K = T.karte
+    n = 8192
+    envs = [T.TarokVecEnv(n, seed=4, mix=K.MIX_ALL) for _ in range(2)]
+    sps = [SP.SelfPlay(e, hidden=256, seed=2, fused_learner=True) for e in envs]
+    for _ in range(3):
+        stats = [sp.iterate(T=24, epochs=1, minibatches=4) for sp in sps]
+        assert stats[0]["loss"] == stats[1]["loss"]
+    assert torch.equal(sps[0].flat, sps[1].flat) and torch.equal(sps[0].adam_m, sps[1].adam_m) and torch.equal(sps[0].adam_v, sps[1].adam_v)
+    for k in ("w1", "w2", "w3", "w3t", "w2t"):
+        assert torch.equal(sps[0]._wf[k], sps[1]._wf[k]), k
+    for e in envs:
+        e.close()
